@@ -1,0 +1,150 @@
+/*
+ * vr_hip.h — C ABI of the MI355X-native volume raycaster (libvr_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of MiroBeno/Volume-Rendering: what happens below
+ * `Renderer::render_volume()` and the three `Renderer::set_*()` calls (reference VolumeRendering/Renderer.h:13-28),
+ * i.e. the work the reference does in GPURenderer1.cu:65-112, GPURenderer23.cu:55-81 and GPURenderer4.cu:89-153.
+ * The host C++ mirror of the reference interface (volume-rendering_amd/csrc/host/Renderer.h, class HipRenderer)
+ * is the intended caller; INTEGRATION.md shows the few lines a maintainer of the reference adds.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++/torch types; every entry point returns 0 on success and a
+ *     non-zero vr_status otherwise; nothing exits the process or throws (the reference's cuda_safe_call
+ *     exit(EXIT_FAILURE) policy, cuda_utils.h:21-31, is deliberately NOT reproduced below the ABI);
+ *   - one opaque vr_ctx per GPU, no globals (the reference keeps everything in statics, Renderer.h:39-43);
+ *   - a context is not thread-safe (neither is the reference);
+ *   - there is NO CPU fallback: without a usable HIP device vr_hip_create() fails with VR_ERR_NO_DEVICE.
+ */
+#ifndef VR_HIP_H
+#define VR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Reference constants, RaycasterBase.h:12-16 */
+#define VR_TF_SIZE          128   /* TF_SIZE: entries of the transfer function (float4 each, premultiplied) */
+#define VR_TF_RATIO         2     /* TF_RATIO = 256 / TF_SIZE */
+#define VR_ESL_VOLUME_DIMS  32    /* ESL_VOLUME_DIMS: empty-space-leaping grid is 32^3 blocks */
+#define VR_ESL_VOLUME_SIZE  1024  /* ESL_VOLUME_SIZE: 32^3 bits = 1024 uint32 words */
+#define VR_ESL_MIN_BLOCK    8     /* ESL_MIN_BLOCK_SIZE */
+
+typedef enum vr_status {
+	VR_OK               = 0,
+	VR_ERR_INVALID      = 1,  /* NULL / out-of-range argument; same value the reference returns (CPURenderer.cpp:44-45) */
+	VR_ERR_NO_DEVICE    = 2,
+	VR_ERR_ALLOC        = 3,  /* device allocation failed (reference: GPURenderer1.cu:91-95 returns 1) */
+	VR_ERR_HIP          = 4,  /* any other HIP runtime error; see vr_hip_last_error() */
+	VR_ERR_NOT_READY    = 5   /* render before set_window / set_transfer_fn / set_volume */
+} vr_status;
+
+typedef enum vr_sampling {
+	VR_SAMPLE_NEAREST   = 0,  /* Model::sample_data (ModelBase.h:17-23) + transfer_fn[sample / TF_RATIO] (CPURenderer.cpp:31):
+	                             semantics of CPURenderer and GPURenderer1/2/3 */
+	VR_SAMPLE_TRILINEAR = 1   /* GPURenderer4 semantics (GPURenderer4.cu:76-77,91-99,136-141): trilinear volume fetch with
+	                             normalised coordinates + clamp addressing, linearly filtered transfer function */
+} vr_sampling;
+
+/* struct View, ViewBase.h:14-21 (dims widened to 32 bit, bool -> uint32) */
+typedef struct vr_view {
+	uint32_t width, height;     /* View::dims */
+	float origin[3];
+	float direction[3];
+	float right_plane[3];
+	float up_plane[3];
+	float light_pos[3];
+	uint32_t perspective;       /* 0 = orthogonal, 1 = perspective */
+} vr_view;
+
+/* The by-value part of struct Raycaster (RaycasterBase.h:20-30) that travels with every render_volume() call,
+ * plus the sampling mode and the screen-space partition used for multi-GPU rendering. */
+typedef struct vr_params {
+	vr_view  view;
+	float    ray_step;          /* Raycaster::ray_step */
+	float    ray_threshold;     /* Raycaster::ray_threshold (early ray termination) */
+	uint32_t esl;               /* Raycaster::esl (empty space leaping on/off) */
+	uint32_t esl_block_dims;    /* Raycaster::esl_block_dims (voxels per ESL block edge) */
+	float    esl_block_size[3]; /* Raycaster::esl_block_size (block edge in model space) */
+	float    light_kd;          /* Raycaster::light_kd */
+	uint32_t sampling;          /* vr_sampling */
+	/* Screen-space partition. The output buffer holds out_rows rows of out_width pixels (RGBA8, row-major, y-up):
+	 *   out[ly * out_width + lx]  <-  frame pixel (x0 + lx, gy)
+	 *   gy = ((ly / band_rows) * band_stride + band_first) * band_rows + ly % band_rows
+	 * Whole frame: x0 = 0, out_width = width, out_rows = height, band_rows = height, band_stride = 1, band_first = 0.
+	 * Rank r of n (interleaved bands of b rows): band_rows = b, band_stride = n, band_first = r.
+	 * Pixels with gy >= height stay cleared. */
+	uint32_t x0, out_width, out_rows;
+	uint32_t band_rows, band_stride, band_first;
+} vr_params;
+
+typedef struct vr_ctx vr_ctx;
+
+/* Per-frame statistics filled in by vr_hip_timing(). */
+typedef struct vr_timing {
+	float    kernel_ms;     /* hipEvent time of the ray-march kernel of the last render (on the render's stream) */
+	float    total_ms;      /* clear + parameter upload + kernel (+ D2H copy for vr_hip_render), the reference's timed region
+	                           (VolR.cpp:109-111, GPURenderer1.cu:107-110) */
+	uint64_t launches;      /* ray-march launches since the last vr_hip_timing_reset() */
+	double   kernel_ms_sum; /* sum of kernel_ms over those launches */
+} vr_timing;
+
+/* ---- lifetime: replaces GPURenderer1::GPURenderer1 / ~GPURenderer1 (GPURenderer1.cu:17-28) ---- */
+int  vr_hip_create(int device, vr_ctx **out);
+void vr_hip_destroy(vr_ctx *ctx);
+const char *vr_hip_last_error(const vr_ctx *ctx);           /* never NULL */
+
+/* ---- Renderer::set_window_buffer(View) — GPURenderer1.cu:74-84: (re)allocates the device framebuffer ---- */
+int vr_hip_set_window(vr_ctx *ctx, uint32_t width, uint32_t height);
+
+/* ---- Renderer::set_transfer_fn(Raycaster) — GPURenderer1.cu:65-72: uploads the premultiplied TF (128 x float4)
+ *      AND the ESL bit-volume (1024 words; bit set = block empty) ---- */
+int vr_hip_set_transfer_fn(vr_ctx *ctx, const float *tf_premult_rgba, const uint32_t *esl_bits);
+
+/* ---- Renderer::set_volume(Model) — GPURenderer1.cu:86-97: copies the host voxels to HBM.
+ *      bytes_per_voxel 1 (reference) or 2 (build-side extension, little-endian u16); sizes are 64-bit inside. ---- */
+int vr_hip_set_volume(vr_ctx *ctx, const void *host_voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                      uint32_t bytes_per_voxel);
+/* same, source already in device memory (x-fastest, unpadded) */
+int vr_hip_set_volume_device(vr_ctx *ctx, const void *dev_voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                             uint32_t bytes_per_voxel);
+
+/* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
+ * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
+ *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.
+ * vr_hip_render_device: `dev_rgba` is a DEVICE pointer (renderer ids 3-4, GPURenderer23.cu:72-81) — clear + kernel on
+ *   `stream` (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host.
+ * Return 0 ok / VR_ERR_INVALID on NULL arguments like the reference (GPURenderer1.cu:101-102). */
+int vr_hip_render(vr_ctx *ctx, const vr_params *params, uint8_t *host_rgba);
+int vr_hip_render_device(vr_ctx *ctx, const vr_params *params, void *dev_rgba, void *stream);
+
+/* ---- timing: replaces the cudaEvent pair of Profiler.cpp:46-67 ---- */
+int vr_hip_timing(vr_ctx *ctx, vr_timing *out);             /* synchronises the pending events */
+int vr_hip_timing_reset(vr_ctx *ctx);
+
+/* ---- feeders of the path on the GPU ----
+ * Per-ESL-block min/max scan of RaycasterBase::set_volume (RaycasterBase.cpp:101-117) as an HBM-streaming reduction
+ * over the resident volume.  minmax_out: 32*32*32 pairs {min,max} (uint8; u16 volumes use the high byte),
+ * index z*1024 + y*32 + x; unused blocks keep {255, 0}.  esl_block_dims_out / esl_block_size_out follow
+ * RaycasterBase.cpp:97-99,118-122.  kernel_ms_out (optional) = hipEvent time of the reduction kernel. */
+int vr_hip_volume_minmax(vr_ctx *ctx, uint8_t *minmax_out, uint32_t *esl_block_dims_out, float *esl_block_size_out,
+                         float *kernel_ms_out);
+/* 256-bin histogram of the resident volume (ModelBase.cpp:19-33 raw counts; u16: high byte). */
+int vr_hip_volume_histogram(vr_ctx *ctx, uint64_t *hist256_out, float *kernel_ms_out);
+
+/* ---- synthetic benchmark volumes generated straight into HBM (SURVEY §8d "shell" / "noise") ----
+ * kind 0 = shell, 1 = noise.  Replaces the resident volume (cube n^3). */
+int vr_hip_generate_volume(vr_ctx *ctx, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bytes_per_voxel);
+/* copy the resident volume back (unpadded, x-fastest) — for checksums and for feeding the CPU baseline */
+int vr_hip_download_volume(vr_ctx *ctx, void *host_out, uint64_t bytes);
+
+/* ---- introspection ---- */
+int vr_hip_device_info(vr_ctx *ctx, char *name_out, size_t name_cap, uint32_t *compute_units, uint64_t *hbm_bytes);
+const char *vr_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_HIP_H */

@@ -1,0 +1,57 @@
+/*
+ * vr_host.h — C wrappers around the host-side C++ mirror of the reference's scene-state managers
+ * (volume-rendering_amd/csrc/host/: ViewBase, RaycasterBase, HipRenderer), exported by libvr_hip.so so that
+ * non-C++ callers (the python bench / test plumbing) can produce exactly the inputs the reference feeds its renderers.
+ * None of these functions touches the GPU except vr_host_render_frame().
+ *
+ * Like the classes they wrap (and like the reference: Renderer.h:39-43, RaycasterBase.h:102-118) the state behind
+ * these calls is process-global and not thread-safe.
+ */
+#ifndef VR_HOST_H
+#define VR_HOST_H
+
+#include "vr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ViewBase (reference ViewBase.cpp) ---- */
+/* One view of the reference's benchmark loop (VolR.cpp:232-248): viewport w x h, projection, then
+ * ViewBase::toggle_perspective(true) and ViewBase::set_camera_position(angles, distance).  Starts from the start-up
+ * camera state each call. */
+int vr_host_benchmark_view(uint32_t width, uint32_t height, uint32_t perspective, const float angles_deg[3],
+                           float distance, vr_view *out);
+/* The 8 views of the benchmark loop in its order: ortho poses 0-3, then perspective poses 0-3;
+ * poses (0,0,0) (-45,-45,0) (90,0,0) (180,90,0) at distance 2. */
+int vr_host_benchmark_view_index(uint32_t width, uint32_t height, uint32_t index /* 0..7 */, vr_view *out);
+
+/* ---- RaycasterBase (reference RaycasterBase.cpp) ---- */
+/* RaycasterBase::reset_transfer_fn() followed by RaycasterBase::set_volume(): the init order of VolR.cpp:416-417.
+ * voxels: host u8 volume (may be NULL if minmax_pairs is given); minmax_pairs: optional 32^3 {min,max} pairs from
+ * vr_hip_volume_minmax (skips the serial host scan). */
+int vr_host_raycaster_set_volume(const uint8_t *voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                                 const uint8_t *minmax_pairs);
+void vr_host_raycaster_reset_transfer_fn(void);
+/* install an edited base (non-premultiplied) TF, 128 x rgba, then RaycasterBase::update_transfer_fn() */
+int vr_host_raycaster_set_base_transfer_fn(const float *base_rgba);
+/* clamped setters: RaycasterBase::change_ray_step / change_ray_threshold / change_light_intensity / toggle_esl */
+void vr_host_raycaster_change_ray_step(float step, int reset);
+void vr_host_raycaster_change_ray_threshold(float threshold, int reset);
+void vr_host_raycaster_change_light_intensity(float intensity, int reset);
+void vr_host_raycaster_set_esl(int on);
+void vr_host_raycaster_reset_ray_step(void);
+/* Snapshot of RaycasterBase::raycaster: fills ray_step, ray_threshold, esl, esl_block_dims, esl_block_size, light_kd
+ * of *params (view / sampling / partition untouched); any of the array outputs may be NULL. */
+int vr_host_raycaster_get(vr_params *params, float *tf_premult_out /*128x4*/, uint32_t *esl_bits_out /*1024*/,
+                          uint8_t *minmax_pairs_out /*32768x2*/, float *base_rgba_out /*128x4*/);
+
+/* ---- one frame through the C++ mirror: HipRenderer(RaycasterBase::raycaster).render_volume(host buffer) ----
+ * Uses the volume previously given to vr_host_raycaster_set_volume (voxels must still be valid) and `view`.
+ * Returns what render_volume returns (0 / 1). */
+int vr_host_render_frame(int device, uint32_t sampling, const vr_view *view, uint8_t *host_rgba);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_HOST_H */

@@ -1,0 +1,22 @@
+"""MI355X-native volume raycaster — python plumbing over the C ABI (include/vr_hip.h, include/vr_host.h).
+
+The product is libvr_hip.so (hand-written gfx950 HIP kernels behind a C ABI that mirrors the reference's
+``Renderer`` plug-in interface, VolumeRendering/Renderer.h:13-28).  This package only loads that library with
+ctypes and adds what python is here for: device buffers / streams (torch) and the multi-GPU frame split
+(torch.distributed over RCCL).  It never imports anything from ``oracle/`` and has no CPU fallback: without the
+built library, or without a GPU, it fails loudly.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("volume-rendering_amd")`` (``__graft_entry__.load_package()`` does that).
+"""
+from .binding import (  # noqa: F401
+    VrError, VrParams, VrView, VrTiming, lib, library_path,
+    SAMPLE_NEAREST, SAMPLE_TRILINEAR, TF_SIZE, ESL_VOLUME_SIZE,
+)
+from .scene import Scene, benchmark_view, whole_frame, band_partition  # noqa: F401
+from .renderer import HipRenderer  # noqa: F401
+
+__all__ = [
+    "VrError", "VrParams", "VrView", "VrTiming", "lib", "library_path", "SAMPLE_NEAREST", "SAMPLE_TRILINEAR",
+    "TF_SIZE", "ESL_VOLUME_SIZE", "Scene", "benchmark_view", "whole_frame", "band_partition", "HipRenderer",
+]

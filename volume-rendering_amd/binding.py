@@ -1,0 +1,104 @@
+"""ctypes declarations of the C ABI in include/vr_hip.h and include/vr_host.h (struct layouts must match)."""
+import ctypes as C
+import os
+
+SAMPLE_NEAREST = 0      # vr_sampling.VR_SAMPLE_NEAREST   — CPURenderer / GPURenderer1-3 semantics
+SAMPLE_TRILINEAR = 1    # vr_sampling.VR_SAMPLE_TRILINEAR — GPURenderer4 semantics
+TF_SIZE = 128
+ESL_VOLUME_SIZE = 1024
+
+_STATUS = {0: "VR_OK", 1: "VR_ERR_INVALID", 2: "VR_ERR_NO_DEVICE", 3: "VR_ERR_ALLOC", 4: "VR_ERR_HIP", 5: "VR_ERR_NOT_READY"}
+
+
+class VrError(RuntimeError):
+    def __init__(self, code, message=""):
+        self.code = code
+        super().__init__(f"{_STATUS.get(code, code)}: {message}" if message else _STATUS.get(code, str(code)))
+
+
+class VrView(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32),
+        ("origin", C.c_float * 3), ("direction", C.c_float * 3), ("right_plane", C.c_float * 3),
+        ("up_plane", C.c_float * 3), ("light_pos", C.c_float * 3), ("perspective", C.c_uint32),
+    ]
+
+
+class VrParams(C.Structure):
+    _fields_ = [
+        ("view", VrView),
+        ("ray_step", C.c_float), ("ray_threshold", C.c_float), ("esl", C.c_uint32), ("esl_block_dims", C.c_uint32),
+        ("esl_block_size", C.c_float * 3), ("light_kd", C.c_float), ("sampling", C.c_uint32),
+        ("x0", C.c_uint32), ("out_width", C.c_uint32), ("out_rows", C.c_uint32),
+        ("band_rows", C.c_uint32), ("band_stride", C.c_uint32), ("band_first", C.c_uint32),
+    ]
+
+    def copy(self):
+        other = VrParams()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(VrParams))
+        return other
+
+
+class VrTiming(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint64), ("kernel_ms_sum", C.c_double)]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvr_hip.so")
+
+
+_lib = None
+
+
+def lib():
+    """Loads libvr_hip.so once.  Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing — build it with `make -C volume-rendering_amd/csrc` "
+                          f"(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    P = C.POINTER
+    vp, u32, u64, f32p = C.c_void_p, C.c_uint32, C.c_uint64, P(C.c_float)
+    sig = {
+        "vr_hip_version": (C.c_char_p, []),
+        "vr_hip_create": (C.c_int, [C.c_int, P(vp)]),
+        "vr_hip_destroy": (None, [vp]),
+        "vr_hip_last_error": (C.c_char_p, [vp]),
+        "vr_hip_set_window": (C.c_int, [vp, u32, u32]),
+        "vr_hip_set_transfer_fn": (C.c_int, [vp, vp, vp]),
+        "vr_hip_set_volume": (C.c_int, [vp, vp, u32, u32, u32, u32]),
+        "vr_hip_set_volume_device": (C.c_int, [vp, vp, u32, u32, u32, u32]),
+        "vr_hip_render": (C.c_int, [vp, P(VrParams), vp]),
+        "vr_hip_render_device": (C.c_int, [vp, P(VrParams), vp, vp]),
+        "vr_hip_timing": (C.c_int, [vp, P(VrTiming)]),
+        "vr_hip_timing_reset": (C.c_int, [vp]),
+        "vr_hip_volume_minmax": (C.c_int, [vp, vp, P(u32), f32p, f32p]),
+        "vr_hip_volume_histogram": (C.c_int, [vp, vp, f32p]),
+        "vr_hip_generate_volume": (C.c_int, [vp, u32, u32, u32, u32]),
+        "vr_hip_download_volume": (C.c_int, [vp, vp, u64]),
+        "vr_hip_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, P(u32), P(u64)]),
+        "vr_host_benchmark_view": (C.c_int, [u32, u32, u32, f32p, C.c_float, P(VrView)]),
+        "vr_host_benchmark_view_index": (C.c_int, [u32, u32, u32, P(VrView)]),
+        "vr_host_raycaster_set_volume": (C.c_int, [vp, u32, u32, u32, vp]),
+        "vr_host_raycaster_reset_transfer_fn": (None, []),
+        "vr_host_raycaster_set_base_transfer_fn": (C.c_int, [vp]),
+        "vr_host_raycaster_change_ray_step": (None, [C.c_float, C.c_int]),
+        "vr_host_raycaster_change_ray_threshold": (None, [C.c_float, C.c_int]),
+        "vr_host_raycaster_change_light_intensity": (None, [C.c_float, C.c_int]),
+        "vr_host_raycaster_set_esl": (None, [C.c_int]),
+        "vr_host_raycaster_reset_ray_step": (None, []),
+        "vr_host_raycaster_get": (C.c_int, [P(VrParams), vp, vp, vp, vp]),
+        "vr_host_render_frame": (C.c_int, [C.c_int, u32, P(VrView), vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)      # AttributeError here = the library does not export what the headers declare
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled lazily by tests from the headers

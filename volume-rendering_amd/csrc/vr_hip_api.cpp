@@ -1,0 +1,366 @@
+// vr_hip_api.cpp — the C ABI of include/vr_hip.h: one opaque context per GPU that owns the device copies of the
+// volume / transfer function / ESL bit-volume / framebuffer and launches the gfx950 kernels of vr_kernels.hip.
+//
+// It replaces the device management the reference spreads over GPURenderer1.cu:17-28,65-112, GPURenderer23.cu:55-81
+// and GPURenderer4.cu:89-153 (static globals, cudaMalloc/cudaMemcpy per set_*, cuda_safe_call -> exit).  Differences
+// by design: no globals, no exit(), errors are return codes + vr_hip_last_error(); the per-frame parameter block is
+// the kernel argument itself (no cudaMemcpyToSymbol per frame, GPURenderer23.cu:65,77); the frame clear is fused into
+// the kernel (no cudaMemset per frame, GPURenderer1.cu:107).  There is no CPU fallback.
+#include "vr_device.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace vr;
+
+namespace {
+
+constexpr int kEventRing = 256;
+
+struct EventPair { hipEvent_t start = nullptr, stop = nullptr; bool pending = false; };
+
+}  // namespace
+
+struct vr_ctx {
+	int device = -1;
+	hipStream_t stream = nullptr;           // context-owned stream for the synchronous entry points
+	// window
+	uint32_t win_w = 0, win_h = 0;
+	void *fb = nullptr; size_t fb_bytes = 0;
+	// transfer function + ESL
+	float *tf = nullptr; uint32_t *esl = nullptr; bool tf_set = false;
+	// volume
+	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
+	// feeders scratch
+	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
+	// timing
+	EventPair ring[kEventRing]; int ring_head = 0;
+	hipEvent_t aux_start = nullptr, aux_stop = nullptr;
+	float last_kernel_ms = 0, last_total_ms = 0; uint64_t launches = 0; double kernel_ms_sum = 0;
+	std::string err;
+};
+
+namespace {
+
+int fail(vr_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+	if (c) {
+		char buf[512];
+		if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int) e);
+		else snprintf(buf, sizeof buf, "%s", what);
+		c->err = buf;
+	}
+	return code;
+}
+
+#define VR_TRY(c, expr)                                                                              \
+	do {                                                                                             \
+		hipError_t e_ = (expr);                                                                      \
+		if (e_ != hipSuccess) {                                                                      \
+			(void) hipGetLastError();                                                                \
+			return fail((c), e_ == hipErrorOutOfMemory ? VR_ERR_ALLOC : VR_ERR_HIP, #expr, e_);      \
+		}                                                                                            \
+	} while (0)
+
+bool finite3(const float *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+// folds one finished event pair into the statistics
+void harvest(vr_ctx *c, EventPair &p) {
+	if (!p.pending) return;
+	float ms = 0;
+	if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+		c->last_kernel_ms = ms; c->kernel_ms_sum += ms; c->launches++;
+	}
+	p.pending = false;
+}
+
+int validate_params(vr_ctx *c, const vr_params *p) {
+	if (p == nullptr) return fail(c, VR_ERR_INVALID, "params is NULL");
+	const vr_view &v = p->view;
+	if (v.width == 0 || v.height == 0 || v.width > 65535u || v.height > 65535u)      // View::dims is ushort2
+		return fail(c, VR_ERR_INVALID, "view dims out of range (1..65535)");
+	if (!finite3(v.origin) || !finite3(v.direction) || !finite3(v.right_plane) || !finite3(v.up_plane) || !finite3(v.light_pos))
+		return fail(c, VR_ERR_INVALID, "view vectors must be finite");
+	if (!(p->ray_step >= 1e-6f) || !std::isfinite(p->ray_step))
+		return fail(c, VR_ERR_INVALID, "ray_step must be finite and >= 1e-6");
+	if (!std::isfinite(p->ray_threshold) || !std::isfinite(p->light_kd))
+		return fail(c, VR_ERR_INVALID, "ray_threshold / light_kd must be finite");
+	if (p->esl && (p->esl_block_dims == 0 || !finite3(p->esl_block_size)))
+		return fail(c, VR_ERR_INVALID, "esl_block_dims must be > 0 and esl_block_size finite when esl is on");
+	if (p->sampling != VR_SAMPLE_NEAREST && p->sampling != VR_SAMPLE_TRILINEAR)
+		return fail(c, VR_ERR_INVALID, "unknown sampling mode");
+	if (p->out_width == 0 || p->out_rows == 0 || p->out_width > 65535u || p->out_rows > 65535u)
+		return fail(c, VR_ERR_INVALID, "out_width / out_rows out of range");
+	if (p->band_rows == 0 || p->band_stride == 0 || p->band_first >= p->band_stride)
+		return fail(c, VR_ERR_INVALID, "band partition invalid (band_rows > 0, band_first < band_stride)");
+	return VR_OK;
+}
+
+int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
+	RayKernelArgs a;
+	memset(&a, 0, sizeof a);
+	a.p = *p;
+	a.dim_x = c->dim[0]; a.dim_y = c->dim[1]; a.dim_z = c->dim[2];
+	a.tiles_x = (p->out_width + 15u) / 16u; a.tiles_y = (p->out_rows + 15u) / 16u;
+	a.stride_y = c->dim[0]; a.stride_z = (uint64_t) c->dim[0] * c->dim[1];
+	a.half_x = 0.5f * (float) c->dim[0]; a.half_y = 0.5f * (float) c->dim[1]; a.half_z = 0.5f * (float) c->dim[2];
+	a.off_x = a.half_x - 0.5f; a.off_y = a.half_y - 0.5f; a.off_z = a.half_z - 0.5f;
+	a.max_x = (float) (c->dim[0] - 1); a.max_y = (float) (c->dim[1] - 1); a.max_z = (float) (c->dim[2] - 1);
+
+	EventPair &ev = c->ring[c->ring_head];
+	c->ring_head = (c->ring_head + 1) % kEventRing;
+	harvest(c, ev);                              // only blocks if 256 launches are still in flight
+	VR_TRY(c, hipEventRecord(ev.start, stream));
+	VR_TRY(c, launch_raymarch(a, c->vol, c->bpv, c->tf, c->esl, dev_rgba, stream));
+	VR_TRY(c, hipEventRecord(ev.stop, stream));
+	ev.pending = true;
+	return VR_OK;
+}
+
+int ready(vr_ctx *c) {
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "render before set_volume");
+	if (!c->tf_set) return fail(c, VR_ERR_NOT_READY, "render before set_transfer_fn");
+	return VR_OK;
+}
+
+int alloc_volume(vr_ctx *c, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
+	if (x == 0 || y == 0 || z == 0 || x > 65535u || y > 65535u || z > 65535u)       // Model::dims is ushort3
+		return fail(c, VR_ERR_INVALID, "volume dims out of range (1..65535)");
+	if (bpv != 1 && bpv != 2) return fail(c, VR_ERR_INVALID, "bytes_per_voxel must be 1 or 2");
+	if (c->vol) { (void) hipFree(c->vol); c->vol = nullptr; }
+	const uint64_t elems = (uint64_t) x * y * z;
+	const uint64_t slack = volume_tail_slack(x, y);
+	VR_TRY(c, hipMalloc(&c->vol, (elems + slack) * bpv));
+	VR_TRY(c, hipMemsetAsync((uint8_t *) c->vol + elems * bpv, 0, slack * bpv, c->stream));
+	c->vol_elems = elems; c->dim[0] = x; c->dim[1] = y; c->dim[2] = z; c->bpv = bpv;
+	return VR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vr_hip_version(void) { return "vr_hip 0.1 (gfx950)"; }
+
+int vr_hip_create(int device, vr_ctx **out) {
+	if (out == nullptr) return VR_ERR_INVALID;
+	*out = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+		(void) hipGetLastError();
+		return VR_ERR_NO_DEVICE;                 // no CPU fallback: the product path needs an MI355X
+	}
+	vr_ctx *c = new (std::nothrow) vr_ctx();
+	if (c == nullptr) return VR_ERR_ALLOC;
+	c->device = device;
+	*out = c;                                    // handed out even on failure below so last_error stays readable
+	VR_TRY(c, hipSetDevice(device));
+	VR_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	VR_TRY(c, hipMalloc((void **) &c->tf, VR_TF_SIZE * 4 * sizeof(float)));
+	VR_TRY(c, hipMalloc((void **) &c->esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t)));
+	VR_TRY(c, hipMalloc((void **) &c->minmax, 32 * 32 * 32 * 2));
+	VR_TRY(c, hipMalloc((void **) &c->hist, 256 * sizeof(unsigned long long)));
+	for (int i = 0; i < kEventRing; i++) {
+		VR_TRY(c, hipEventCreate(&c->ring[i].start));
+		VR_TRY(c, hipEventCreate(&c->ring[i].stop));
+	}
+	VR_TRY(c, hipEventCreate(&c->aux_start));
+	VR_TRY(c, hipEventCreate(&c->aux_stop));
+	return VR_OK;
+}
+
+void vr_hip_destroy(vr_ctx *c) {
+	if (c == nullptr) return;
+	(void) hipSetDevice(c->device);
+	if (c->stream) (void) hipStreamSynchronize(c->stream);
+	for (int i = 0; i < kEventRing; i++) {
+		if (c->ring[i].start) (void) hipEventDestroy(c->ring[i].start);
+		if (c->ring[i].stop) (void) hipEventDestroy(c->ring[i].stop);
+	}
+	if (c->aux_start) (void) hipEventDestroy(c->aux_start);
+	if (c->aux_stop) (void) hipEventDestroy(c->aux_stop);
+	if (c->fb) (void) hipFree(c->fb);
+	if (c->tf) (void) hipFree(c->tf);
+	if (c->esl) (void) hipFree(c->esl);
+	if (c->vol) (void) hipFree(c->vol);
+	if (c->minmax) (void) hipFree(c->minmax);
+	if (c->hist) (void) hipFree(c->hist);
+	if (c->stream) (void) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+const char *vr_hip_last_error(const vr_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int vr_hip_set_window(vr_ctx *c, uint32_t w, uint32_t h) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (w == 0 || h == 0 || w > 65535u || h > 65535u) return fail(c, VR_ERR_INVALID, "window dims out of range (1..65535)");
+	VR_TRY(c, hipSetDevice(c->device));
+	const size_t bytes = (size_t) w * h * 4;
+	if (bytes != c->fb_bytes) {
+		if (c->fb) { (void) hipFree(c->fb); c->fb = nullptr; c->fb_bytes = 0; }
+		VR_TRY(c, hipMalloc(&c->fb, bytes));
+		c->fb_bytes = bytes;
+	}
+	c->win_w = w; c->win_h = h;
+	return VR_OK;
+}
+
+int vr_hip_set_transfer_fn(vr_ctx *c, const float *tf, const uint32_t *esl) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (tf == nullptr || esl == nullptr) return fail(c, VR_ERR_INVALID, "transfer_fn / esl_volume is NULL");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, hipMemcpy(c->tf, tf, VR_TF_SIZE * 4 * sizeof(float), hipMemcpyHostToDevice));
+	VR_TRY(c, hipMemcpy(c->esl, esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t), hipMemcpyHostToDevice));
+	c->tf_set = true;
+	return VR_OK;
+}
+
+int vr_hip_set_volume(vr_ctx *c, const void *host, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (host == nullptr) return fail(c, VR_ERR_INVALID, "volume data is NULL");     // GPURenderer1.cu:91-92
+	VR_TRY(c, hipSetDevice(c->device));
+	int rc = alloc_volume(c, x, y, z, bpv);
+	if (rc) return rc;
+	VR_TRY(c, hipMemcpy(c->vol, host, c->vol_elems * bpv, hipMemcpyHostToDevice));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	return VR_OK;
+}
+
+int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (dev == nullptr) return fail(c, VR_ERR_INVALID, "volume data is NULL");
+	VR_TRY(c, hipSetDevice(c->device));
+	int rc = alloc_volume(c, x, y, z, bpv);
+	if (rc) return rc;
+	VR_TRY(c, hipMemcpy(c->vol, dev, c->vol_elems * bpv, hipMemcpyDeviceToDevice));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	return VR_OK;
+}
+
+int vr_hip_render_device(vr_ctx *c, const vr_params *p, void *dev_rgba, void *stream) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (dev_rgba == nullptr) return fail(c, VR_ERR_INVALID, "buffer is NULL");      // GPURenderer1.cu:101-102
+	int rc = validate_params(c, p);
+	if (rc) return rc;
+	rc = ready(c);
+	if (rc) return rc;
+	VR_TRY(c, hipSetDevice(c->device));
+	return launch_frame(c, p, dev_rgba, stream ? (hipStream_t) stream : c->stream);
+}
+
+int vr_hip_render(vr_ctx *c, const vr_params *p, uint8_t *host_rgba) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (host_rgba == nullptr) return fail(c, VR_ERR_INVALID, "buffer is NULL");
+	int rc = validate_params(c, p);
+	if (rc) return rc;
+	rc = ready(c);
+	if (rc) return rc;
+	const size_t bytes = (size_t) p->out_width * p->out_rows * 4;
+	if (c->fb == nullptr || bytes > c->fb_bytes)
+		return fail(c, VR_ERR_NOT_READY, "output larger than the window buffer: call vr_hip_set_window first");
+	VR_TRY(c, hipSetDevice(c->device));
+	const auto t0 = std::chrono::steady_clock::now();
+	rc = launch_frame(c, p, c->fb, c->stream);
+	if (rc) return rc;
+	VR_TRY(c, hipMemcpyAsync(host_rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	const auto t1 = std::chrono::steady_clock::now();
+	c->last_total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+	return VR_OK;
+}
+
+int vr_hip_timing(vr_ctx *c, vr_timing *out) {
+	if (c == nullptr || out == nullptr) return VR_ERR_INVALID;
+	(void) hipSetDevice(c->device);
+	for (int i = 0; i < kEventRing; i++)
+		harvest(c, c->ring[(c->ring_head + i) % kEventRing]);    // oldest first
+	out->kernel_ms = c->last_kernel_ms;
+	out->total_ms = c->last_total_ms > 0 ? c->last_total_ms : c->last_kernel_ms;
+	out->launches = c->launches;
+	out->kernel_ms_sum = c->kernel_ms_sum;
+	return VR_OK;
+}
+
+int vr_hip_timing_reset(vr_ctx *c) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	vr_timing t;
+	(void) vr_hip_timing(c, &t);
+	c->launches = 0; c->kernel_ms_sum = 0; c->last_kernel_ms = 0; c->last_total_ms = 0;
+	return VR_OK;
+}
+
+int vr_hip_volume_minmax(vr_ctx *c, uint8_t *minmax_out, uint32_t *bd_out, float *bs_out, float *kernel_ms_out) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (minmax_out == nullptr) return fail(c, VR_ERR_INVALID, "minmax_out is NULL");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "minmax before set_volume");
+	VR_TRY(c, hipSetDevice(c->device));
+	// RaycasterBase.cpp:97-99
+	uint32_t max_dim = c->dim[0] > c->dim[1] ? c->dim[0] : c->dim[1];
+	if (c->dim[2] > max_dim) max_dim = c->dim[2];
+	uint32_t bd = (max_dim + VR_ESL_VOLUME_DIMS - 1) / VR_ESL_VOLUME_DIMS;
+	if (bd < VR_ESL_MIN_BLOCK) bd = VR_ESL_MIN_BLOCK;
+	VR_TRY(c, hipEventRecord(c->aux_start, c->stream));
+	VR_TRY(c, launch_minmax(c->vol, c->bpv, c->dim[0], c->dim[1], c->dim[2], bd, c->minmax, c->stream));
+	VR_TRY(c, hipEventRecord(c->aux_stop, c->stream));
+	VR_TRY(c, hipMemcpyAsync(minmax_out, c->minmax, 32 * 32 * 32 * 2, hipMemcpyDeviceToHost, c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	if (kernel_ms_out) VR_TRY(c, hipEventElapsedTime(kernel_ms_out, c->aux_start, c->aux_stop));
+	if (bd_out) *bd_out = bd;
+	if (bs_out) {                                // RaycasterBase.cpp:118-122
+		bs_out[0] = 2.0f * (float) bd / (float) c->dim[0];
+		bs_out[1] = 2.0f * (float) bd / (float) c->dim[1];
+		bs_out[2] = 2.0f * (float) bd / (float) c->dim[2];
+	}
+	return VR_OK;
+}
+
+int vr_hip_volume_histogram(vr_ctx *c, uint64_t *hist_out, float *kernel_ms_out) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (hist_out == nullptr) return fail(c, VR_ERR_INVALID, "hist_out is NULL");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "histogram before set_volume");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, hipEventRecord(c->aux_start, c->stream));
+	VR_TRY(c, launch_histogram(c->vol, c->bpv, c->vol_elems, c->hist, c->stream));
+	VR_TRY(c, hipEventRecord(c->aux_stop, c->stream));
+	VR_TRY(c, hipMemcpyAsync(hist_out, c->hist, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	if (kernel_ms_out) VR_TRY(c, hipEventElapsedTime(kernel_ms_out, c->aux_start, c->aux_stop));
+	return VR_OK;
+}
+
+int vr_hip_generate_volume(vr_ctx *c, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bpv) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (kind > 1) return fail(c, VR_ERR_INVALID, "unknown synthetic volume kind");
+	VR_TRY(c, hipSetDevice(c->device));
+	int rc = alloc_volume(c, n, n, n, bpv);
+	if (rc) return rc;
+	VR_TRY(c, launch_generate(c->vol, kind, n, seed, bpv, c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
+	return VR_OK;
+}
+
+int vr_hip_download_volume(vr_ctx *c, void *host_out, uint64_t bytes) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (host_out == nullptr) return fail(c, VR_ERR_INVALID, "host_out is NULL");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "download before set_volume");
+	if (bytes != c->vol_elems * c->bpv) return fail(c, VR_ERR_INVALID, "byte count does not match the resident volume");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, hipMemcpy(host_out, c->vol, bytes, hipMemcpyDeviceToHost));
+	return VR_OK;
+}
+
+int vr_hip_device_info(vr_ctx *c, char *name_out, size_t name_cap, uint32_t *cus, uint64_t *hbm_bytes) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	hipDeviceProp_t prop;
+	VR_TRY(c, hipGetDeviceProperties(&prop, c->device));
+	if (name_out && name_cap) { snprintf(name_out, name_cap, "%s (%s)", prop.name, prop.gcnArchName); }
+	if (cus) *cus = (uint32_t) prop.multiProcessorCount;
+	if (hbm_bytes) *hbm_bytes = (uint64_t) prop.totalGlobalMem;
+	return VR_OK;
+}
+
+}  // extern "C"

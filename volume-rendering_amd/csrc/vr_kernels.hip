@@ -1,0 +1,544 @@
+// vr_kernels.hip — gfx950 (CDNA4) kernels of the volume raycaster.  Written for MI355X only.
+//
+// The hot path: per-pixel ray generation, cube intersection, empty-space leaping, ray-march with NEAREST or manual
+// TRILINEAR sampling of a volume held in linear HBM, transfer-function lookup from an LDS-staged table, optional
+// diffuse shading, front-to-back compositing with a wavefront-ballot early-ray-termination test, RGBA8 store.
+// What it computes is the reference's render_ray (CPURenderer.cpp:11-41 for NEAREST, GPURenderer4.cu:53-87 for
+// TRILINEAR); how it is laid out is not:
+//   * one 64-lane wavefront owns one 8x8-pixel screen tile, a 256-thread workgroup owns a 16x16 tile;
+//   * the transfer function (+ per-entry deltas for the filtered lookup) and the ESL bit-volume live in LDS;
+//   * the loop runs while __ballot(alive) != 0 — a scalar branch on the wave's 64-bit exec summary;
+//   * workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous band of screen tiles;
+//   * the frame clear is fused: every pixel of the output is written exactly once (misses write 0), there is no
+//     separate memset pass over the framebuffer (the reference clears first, CPURenderer.cpp:47).
+//
+// Numerics.  This file is compiled with -ffp-contract=off.  NEAREST mode keeps the reference's float operation order
+// expression by expression (IEEE divide / sqrt, no fused ops), so its output is bit-identical to the reference's CPU
+// renderer.  TRILINEAR mode is defined with explicit fused multiply-adds (oracle/vr_oracle.c states the same sequence).
+#include "vr_device.h"
+
+namespace vr {
+
+#define VR_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+// common.h:88-96 flmin/flmax — written as the reference's ternaries (NaN behaviour included)
+__device__ __forceinline__ float flmin(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float flmax(float a, float b) { return a > b ? a : b; }
+
+// common.h:105-110 map_float_int
+__device__ __forceinline__ uint32_t map_float_int(float f, uint32_t n) {
+	int i = (int) (f * (float) n);
+	if (i >= (int) n) i = (int) n - 1;
+	if (i < 0) i = 0;
+	return (uint32_t) i;
+}
+
+// LDS image, one per workgroup
+struct __attribute__((aligned(16))) LdsTables {
+	f4 tf[VR_TF_SIZE + 1];         // premultiplied TF; entry 128 duplicates 127 (clamp addressing of the filtered lookup)
+	f4 dtf[VR_TF_SIZE + 1];        // dtf[i] = tf[i+1] - tf[i] (same fp32 subtraction the lerp would do per sample)
+	uint32_t esl[VR_ESL_VOLUME_SIZE];
+};
+
+template <int BPV> struct VoxelT;
+template <> struct VoxelT<1> { typedef uint8_t type; };
+template <> struct VoxelT<2> { typedef uint16_t type; };
+
+// ---- volume fetch --------------------------------------------------------------------------------------------
+
+template <int BPV, bool WIDE>
+__device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, uint32_t ix, uint32_t iy, uint32_t iz) {
+	typedef typename VoxelT<BPV>::type V;
+	if (WIDE) {
+		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
+		return ((const V *) vol)[idx];
+	} else {
+		uint32_t idx = (iz * a.dim_y + iy) * a.dim_x + ix;
+		return ((const V *) vol)[idx];
+	}
+}
+
+// ModelBase.h:17-23 Model::sample_data
+template <int BPV, bool WIDE>
+__device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKernelArgs &a, f3 pos) {
+	uint32_t iz = map_float_int((pos.z + 1) * 0.5f, a.dim_z);
+	uint32_t iy = map_float_int((pos.y + 1) * 0.5f, a.dim_y);
+	uint32_t ix = map_float_int((pos.x + 1) * 0.5f, a.dim_x);
+	return fetch_voxel<BPV, WIDE>(vol, a, ix, iy, iz);
+}
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
+__device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
+
+// Two x-adjacent voxels with ONE load: the pair (ix, ix+1) is contiguous in the linear layout.  The address has only
+// voxel alignment (gfx950 global loads accept that); the upper face reads one element into the zeroed tail slack,
+// where the weight is exactly 0.
+template <int BPV>
+__device__ __forceinline__ void load_pair(const void *vol, uint64_t elem, float &v0, float &v1) {
+	if (BPV == 1) {
+		uint16_t w;
+		__builtin_memcpy(&w, (const uint8_t *) vol + elem, 2);
+		v0 = (float) (w & 0xffu); v1 = (float) (w >> 8);
+	} else {
+		uint32_t w;
+		__builtin_memcpy(&w, (const uint8_t *) vol + elem * 2, 4);
+		v0 = (float) (w & 0xffffu); v1 = (float) (w >> 16);
+	}
+}
+
+// Manual trilinear fetch = tex3D with normalised coordinates, linear filter, clamp addressing
+// (GPURenderer4.cu:76,136-141).  xb = fma(pos, N/2, N/2 - 0.5) clamped to [0, N-1] is equivalent to clamping the two
+// neighbour indices: below 0 and above N-1 both neighbours clamp to the same voxel, and lerp(a, a, t) == a exactly.
+template <int BPV, bool WIDE>
+__device__ __forceinline__ float sample_trilinear(const void *vol, const RayKernelArgs &a, f3 pos) {
+	float xb = clampf(VR_FMA(pos.x, a.half_x, a.off_x), 0.0f, a.max_x);
+	float yb = clampf(VR_FMA(pos.y, a.half_y, a.off_y), 0.0f, a.max_y);
+	float zb = clampf(VR_FMA(pos.z, a.half_z, a.off_z), 0.0f, a.max_z);
+	float fx = __builtin_floorf(xb), fy = __builtin_floorf(yb), fz = __builtin_floorf(zb);
+	float ax = xb - fx, ay = yb - fy, az = zb - fz;
+	uint32_t ix = (uint32_t) (int) fx, iy = (uint32_t) (int) fy, iz = (uint32_t) (int) fz;
+	float v000, v100, v010, v110, v001, v101, v011, v111;
+	if (WIDE) {
+		uint64_t e = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
+		load_pair<BPV>(vol, e, v000, v100);
+		load_pair<BPV>(vol, e + a.stride_y, v010, v110);
+		load_pair<BPV>(vol, e + a.stride_z, v001, v101);
+		load_pair<BPV>(vol, e + a.stride_z + a.stride_y, v011, v111);
+	} else {
+		uint32_t e = (iz * a.dim_y + iy) * a.dim_x + ix;
+		uint32_t sy = (uint32_t) a.stride_y, sz = (uint32_t) a.stride_z;
+		load_pair<BPV>(vol, e, v000, v100);
+		load_pair<BPV>(vol, e + sy, v010, v110);
+		load_pair<BPV>(vol, e + sz, v001, v101);
+		load_pair<BPV>(vol, e + sz + sy, v011, v111);
+	}
+	float c00 = lerp(v000, v100, ax), c10 = lerp(v010, v110, ax);
+	float c01 = lerp(v001, v101, ax), c11 = lerp(v011, v111, ax);
+	float c0 = lerp(c00, c10, ay), c1 = lerp(c01, c11, ay);
+	float c = lerp(c0, c1, az);
+	return c * (BPV == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
+}
+
+// ---- per-ray helpers (reference order of operations) ------------------------------------------------------------
+
+// RaycasterBase.h:32-42 Raycaster::intersect; min_bound = (-1,-1,-1) (ModelBase.cpp:10-14)
+__device__ __forceinline__ bool intersect(f3 pt, f3 dir, float &kx, float &ky) {
+	if (dir.x == 0) dir.x = 0.00001f;
+	if (dir.y == 0) dir.y = 0.00001f;
+	if (dir.z == 0) dir.z = 0.00001f;
+	const float mb = -1.0f, nb = 1.0f;
+	f3 k1 = mk3((mb - pt.x) / dir.x, (mb - pt.y) / dir.y, (mb - pt.z) / dir.z);
+	f3 k2 = mk3((nb - pt.x) / dir.x, (nb - pt.y) / dir.y, (nb - pt.z) / dir.z);
+	kx = flmax(flmax(flmin(k1.x, k2.x), flmin(k1.y, k2.y)), flmin(k1.z, k2.z));
+	ky = flmin(flmin(flmax(k1.x, k2.x), flmax(k1.y, k2.y)), flmax(k1.z, k2.z));
+	kx = flmax(kx, 0);
+	return (kx < ky) && (ky > 0);
+}
+
+// RaycasterBase.h:52-65 Raycaster::sample_data_esl — bit set = block is empty; table read from LDS
+__device__ __forceinline__ bool block_empty(const LdsTables &t, const RayKernelArgs &a, f3 pos) {
+	const uint32_t bd = a.p.esl_block_dims;
+	uint32_t index = ((map_float_int((pos.z + 1) * 0.5f, a.dim_z) / bd) * VR_ESL_VOLUME_DIMS +
+	                  (map_float_int((pos.y + 1) * 0.5f, a.dim_y) / bd)) & 0xffffu;
+	uint32_t word = t.esl[index & (VR_ESL_VOLUME_SIZE - 1)];
+	uint32_t bit = map_float_int((pos.x + 1) * 0.5f, a.dim_x) / bd;
+	return (word & (1u << (bit & 31u))) != 0;
+}
+
+// RaycasterBase.h:67-85 Raycaster::leap_empty_space
+__device__ __forceinline__ float leap_empty_space(const RayKernelArgs &a, f3 pt, f3 dir) {
+	const uint32_t bd = a.p.esl_block_dims;
+	uint32_t ix = map_float_int((pt.x + 1) * 0.5f, a.dim_x) / bd;
+	uint32_t iy = map_float_int((pt.y + 1) * 0.5f, a.dim_y) / bd;
+	uint32_t iz = map_float_int((pt.z + 1) * 0.5f, a.dim_z) / bd;
+	if (dir.x > 0) ix++;
+	if (dir.y > 0) iy++;
+	if (dir.z > 0) iz++;
+	f3 kp = mk3(((-1.0f + a.p.esl_block_size[0] * (float) ix) - pt.x) / dir.x,
+	            ((-1.0f + a.p.esl_block_size[1] * (float) iy) - pt.y) / dir.y,
+	            ((-1.0f + a.p.esl_block_size[2] * (float) iz) - pt.z) / dir.z);
+	if (dir.x == 0) kp.x = 100;
+	if (dir.y == 0) kp.y = 100;
+	if (dir.z == 0) kp.z = 100;
+	float dk = flmin(kp.x, kp.y);
+	dk = flmin(dk, kp.z);
+	dk = flmax(dk, 0);
+	return __builtin_floorf(dk / a.p.ray_step) * a.p.ray_step;
+}
+
+template <int SAMPLING>
+__device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
+	if (SAMPLING == VR_SAMPLE_NEAREST)       // CPURenderer.cpp:17,24,38: origin + (direction * k), two roundings
+		return mk3(origin.x + dir.x * k, origin.y + dir.y * k, origin.z + dir.z * k);
+	return mk3(VR_FMA(dir.x, k, origin.x), VR_FMA(dir.y, k, origin.y), VR_FMA(dir.z, k, origin.z));
+}
+
+// ---- the ray-march kernel ------------------------------------------------------------------------------------------
+
+template <int SAMPLING, int BPV, bool WIDE>
+__global__ __launch_bounds__(256)
+void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
+                     const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
+	__shared__ LdsTables lds;
+
+	// -- stage TF (+ deltas) and the ESL bit-volume in LDS
+	{
+		const uint32_t t = threadIdx.x;
+		if (t <= VR_TF_SIZE) {
+			const f4 *tf4 = (const f4 *) tf_g;
+			uint32_t i0 = t < VR_TF_SIZE ? t : VR_TF_SIZE - 1;
+			uint32_t i1 = t + 1 < VR_TF_SIZE ? t + 1 : VR_TF_SIZE - 1;
+			f4 c0 = tf4[i0], c1 = tf4[i1];
+			lds.tf[t] = c0;
+			f4 d; d.x = c1.x - c0.x; d.y = c1.y - c0.y; d.z = c1.z - c0.z; d.w = c1.w - c0.w;
+			lds.dtf[t] = d;
+		}
+		const uint4 *e4 = (const uint4 *) esl_g;
+		((uint4 *) lds.esl)[t] = e4[t];            // 256 threads x 16 B = 4 KiB
+	}
+	__syncthreads();
+
+	// -- XCD-aware workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2):
+	//    give XCD x the x-th contiguous chunk of the row-major tile list, so tiles that share voxel rows share an L2.
+	const uint32_t ntiles = a.tiles_x * a.tiles_y;
+	const uint32_t bid = blockIdx.x;
+	const uint32_t xcd = bid & 7u, slot = bid >> 3;
+	const uint32_t q = ntiles >> 3, r = ntiles & 7u;
+	const uint32_t tile = xcd * q + (xcd < r ? xcd : r) + slot;   // bijective for every ntiles
+	const uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
+
+	// -- one wavefront = one 8x8 pixel tile; 4 waves = 16x16
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t lx = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
+	const uint32_t ly = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
+	if (lx >= a.p.out_width || ly >= a.p.out_rows)
+		return;                                     // no barrier below this point
+	const uint32_t band = ly / a.p.band_rows;
+	const uint32_t gy = (band * a.p.band_stride + a.p.band_first) * a.p.band_rows + (ly - band * a.p.band_rows);
+	const uint32_t gx = a.p.x0 + lx;
+	uint32_t *out_px = out + (size_t) ly * a.p.out_width + lx;
+
+	// -- View::get_ray (ViewBase.h:23-35)
+	f3 origin, dir;
+	bool alive = gx < a.p.view.width && gy < a.p.view.height;
+	{
+		const f3 vo = ld3(a.p.view.origin), vd = ld3(a.p.view.direction);
+		const f3 vr_ = ld3(a.p.view.right_plane), vu = ld3(a.p.view.up_plane);
+		const float fx = (float) ((int) gx - (int) (a.p.view.width / 2u));
+		const float fy = (float) ((int) gy - (int) (a.p.view.height / 2u));
+		if (a.p.view.perspective) {
+			origin = vo;
+			dir = mk3(vd.x + vr_.x * fx, vd.y + vr_.y * fx, vd.z + vr_.z * fx);
+			dir = mk3(dir.x + vu.x * fy, dir.y + vu.y * fy, dir.z + vu.z * fy);
+		} else {
+			dir = vd;
+			origin = mk3(vo.x + vr_.x * fx, vo.y + vr_.y * fx, vo.z + vr_.z * fx);
+			origin = mk3(origin.x + vu.x * fy, origin.y + vu.y * fy, origin.z + vu.z * fy);
+		}
+	}
+	float kx = 0, ky = 0;
+	alive = alive && intersect(origin, dir, kx, ky);
+	const bool hit = alive;
+	const float step = a.p.ray_step;
+	f3 pt = march_point<SAMPLING>(origin, dir, kx);
+
+	// -- empty space leaping loop (CPURenderer.cpp:18-25)
+	if (a.p.esl) {
+		bool probing = alive;
+		uint32_t guard = kMaxRaySteps;
+		while (__ballot(probing) != 0ull) {
+			if (probing) {
+				if (kx <= ky && block_empty(lds, a, pt)) {
+					kx += leap_empty_space(a, pt, dir);
+					kx += step;
+					pt = march_point<SAMPLING>(origin, dir, kx);
+				} else {
+					probing = false;
+				}
+				if (--guard == 0) probing = false;
+			}
+		}
+	}
+	alive = alive && (kx <= ky);                    // CPURenderer.cpp:26-27: fully empty ray — pixel keeps the clear value
+	const bool visible = alive;
+
+	// -- colour accumulation loop (CPURenderer.cpp:29-39 / GPURenderer4.cu:75-86), front to back, premultiplied
+	f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+	const f3 light = ld3(a.p.view.light_pos);
+	const float kd = a.p.light_kd;
+	const bool lit = kd > 0.01f;
+	const float threshold = a.p.ray_threshold;
+	uint32_t guard = kMaxRaySteps;
+	while (__ballot(alive) != 0ull) {               // wave-uniform exit: every lane terminated (ERT) or left the cube
+		if (alive) {
+			f4 cur;
+			if (SAMPLING == VR_SAMPLE_NEAREST) {
+				const uint32_t s = sample_nearest<BPV, WIDE>(vol, a, pt);
+				cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];          // CPURenderer.cpp:31
+				if (cur.w > 0.05f && lit) {                                       // RaycasterBase.h:87-98 shade
+					const float raw = BPV == 1 ? 255.0f : 65535.0f;
+					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
+					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
+					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
+					float sl = (float) sample_nearest<BPV, WIDE>(vol, a, ps) / raw;
+					float diffuse = (sl - (float) s / raw) * kd;
+					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
+				}
+				const float t = 1 - acc.w;                                        // CPURenderer.cpp:34
+				acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
+				acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
+			} else {
+				const float s = sample_trilinear<BPV, WIDE>(vol, a, pt);          // GPURenderer4.cu:76
+				{                                                                  // GPURenderer4.cu:77 filtered TF
+					float xb = clampf(VR_FMA(s, (float) VR_TF_SIZE, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+					float fl = __builtin_floorf(xb);
+					float w = xb - fl;
+					uint32_t i = (uint32_t) (int) fl;
+					f4 c0 = lds.tf[i], dc = lds.dtf[i];
+					cur.x = VR_FMA(w, dc.x, c0.x); cur.y = VR_FMA(w, dc.y, c0.y);
+					cur.z = VR_FMA(w, dc.z, c0.z); cur.w = VR_FMA(w, dc.w, c0.w);
+				}
+				if (cur.w > 0.05f && lit) {                                       // GPURenderer4.cu:41-51 shade_texture
+					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
+					float inv = 1.0f / __builtin_sqrtf(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
+					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
+					f3 ps = mk3(VR_FMA(l.x, 0.01f, pt.x), VR_FMA(l.y, 0.01f, pt.y), VR_FMA(l.z, 0.01f, pt.z));
+					float sl = sample_trilinear<BPV, WIDE>(vol, a, ps);
+					float diffuse = (sl - s) * kd;
+					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
+				}
+				const float t = 1 - acc.w;
+				acc.x = VR_FMA(cur.x, t, acc.x); acc.y = VR_FMA(cur.y, t, acc.y);
+				acc.z = VR_FMA(cur.z, t, acc.z); acc.w = VR_FMA(cur.w, t, acc.w);
+			}
+			if (acc.w > threshold) {                // early ray termination (CPURenderer.cpp:35-36)
+				alive = false;
+			} else {
+				kx += step;
+				pt = march_point<SAMPLING>(origin, dir, kx);
+				alive = (kx <= ky) && (--guard != 0);
+			}
+		}
+	}
+
+	// -- RaycasterBase.h:44-50 write_color (+ the fused clear: misses and fully-empty rays store 0)
+	uint32_t rgba = 0;
+	if (hit && visible) {
+		rgba = map_float_int(acc.x, 256) | (map_float_int(acc.y, 256) << 8) |
+		       (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
+	}
+	*out_px = rgba;
+}
+
+template <int SAMPLING, int BPV, bool WIDE>
+static hipError_t launch_variant(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
+                                 void *out, hipStream_t stream) {
+	const uint32_t ntiles = a.tiles_x * a.tiles_y;
+	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, WIDE>), dim3(ntiles), dim3(256), 0, stream,
+	                   a, volume, tf, esl, (uint32_t *) out);
+	return hipGetLastError();
+}
+
+hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bpv, const float *tf,
+                           const uint32_t *esl, void *out, hipStream_t stream) {
+	// 32-bit element offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size);
+	// larger ones (BASELINE config 5: 2048^3) take the 64-bit path.
+	const uint64_t elems = (uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y);
+	const bool wide = elems * bpv >= (1ull << 32);
+	const bool tri = a.p.sampling == VR_SAMPLE_TRILINEAR;
+	if (bpv == 1) {
+		if (tri) return wide ? launch_variant<VR_SAMPLE_TRILINEAR, 1, true>(a, volume, tf, esl, out, stream)
+		                     : launch_variant<VR_SAMPLE_TRILINEAR, 1, false>(a, volume, tf, esl, out, stream);
+		return wide ? launch_variant<VR_SAMPLE_NEAREST, 1, true>(a, volume, tf, esl, out, stream)
+		            : launch_variant<VR_SAMPLE_NEAREST, 1, false>(a, volume, tf, esl, out, stream);
+	}
+	if (tri) return wide ? launch_variant<VR_SAMPLE_TRILINEAR, 2, true>(a, volume, tf, esl, out, stream)
+	                     : launch_variant<VR_SAMPLE_TRILINEAR, 2, false>(a, volume, tf, esl, out, stream);
+	return wide ? launch_variant<VR_SAMPLE_NEAREST, 2, true>(a, volume, tf, esl, out, stream)
+	            : launch_variant<VR_SAMPLE_NEAREST, 2, false>(a, volume, tf, esl, out, stream);
+}
+
+// ---- feeders: per-ESL-block min/max (RaycasterBase.cpp:101-117) as an HBM-streaming reduction --------------------------
+//
+// One workgroup per (y-block, z-block) pair: it streams block_dims^2 rows of dim_x voxels with 16-byte loads and keeps
+// the 32 x-block minima/maxima in LDS.  min/max are order independent, so the result equals the serial scan exactly.
+
+__device__ __forceinline__ void minmax16(uint4 v, uint32_t &mn, uint32_t &mx) {
+	const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+	#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			uint32_t s = (w[i] >> (8 * b)) & 0xffu;
+			mn = s < mn ? s : mn; mx = s > mx ? s : mx;
+		}
+	}
+}
+
+template <int BPV>
+__global__ __launch_bounds__(256)
+void minmax_kernel(const void *__restrict__ vol, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t bd,
+                   uint8_t *__restrict__ minmax) {
+	__shared__ uint32_t smin[VR_ESL_VOLUME_DIMS], smax[VR_ESL_VOLUME_DIMS];
+	const uint32_t yb = blockIdx.x, zb = blockIdx.y;
+	if (threadIdx.x < VR_ESL_VOLUME_DIMS) { smin[threadIdx.x] = 255u; smax[threadIdx.x] = 0u; }
+	__syncthreads();
+	const uint32_t y0 = yb * bd, z0 = zb * bd;
+	const uint32_t ny = min(bd, dim_y - y0), nz = min(bd, dim_z - z0);
+	const uint32_t rows = ny * nz;
+	const uint64_t row_bytes = (uint64_t) dim_x * BPV;
+	const uint32_t chunk_voxels = 16 / BPV;
+	// fast path: every 16-byte chunk lies inside one x-block and rows are 16-byte aligned
+	const bool fast = (dim_x % chunk_voxels == 0) && (bd % chunk_voxels == 0);
+	if (fast) {
+		const uint32_t chunks_per_row = dim_x / chunk_voxels;
+		const uint64_t total = (uint64_t) rows * chunks_per_row;
+		for (uint64_t c = threadIdx.x; c < total; c += 256) {
+			const uint32_t row = (uint32_t) (c / chunks_per_row), cx = (uint32_t) (c - (uint64_t) row * chunks_per_row);
+			const uint32_t y = y0 + row % ny, z = z0 + row / ny;
+			const uint8_t *p = (const uint8_t *) vol + ((uint64_t) z * dim_y + y) * row_bytes + (uint64_t) cx * 16;
+			const uint4 v = *(const uint4 *) p;
+			uint32_t mn = 255u, mx = 0u;
+			if (BPV == 1) {
+				minmax16(v, mn, mx);
+			} else {                                     // u16: ESL works on the high byte
+				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+				#pragma unroll
+				for (int i = 0; i < 4; i++) {
+					uint32_t s0 = (w[i] >> 8) & 0xffu, s1 = w[i] >> 24;
+					mn = min(mn, min(s0, s1)); mx = max(mx, max(s0, s1));
+				}
+			}
+			const uint32_t xb = (cx * chunk_voxels) / bd;
+			atomicMin(&smin[xb], mn);
+			atomicMax(&smax[xb], mx);
+		}
+	} else {
+		const uint64_t total = (uint64_t) rows * dim_x;
+		for (uint64_t i = threadIdx.x; i < total; i += 256) {
+			const uint32_t row = (uint32_t) (i / dim_x), x = (uint32_t) (i - (uint64_t) row * dim_x);
+			const uint32_t y = y0 + row % ny, z = z0 + row / ny;
+			const uint64_t e = ((uint64_t) z * dim_y + y) * dim_x + x;
+			const uint32_t s = BPV == 1 ? ((const uint8_t *) vol)[e] : (uint32_t) (((const uint16_t *) vol)[e] >> 8);
+			atomicMin(&smin[x / bd], s);
+			atomicMax(&smax[x / bd], s);
+		}
+	}
+	__syncthreads();
+	const uint32_t nxb = (dim_x + bd - 1) / bd;
+	if (threadIdx.x < nxb && threadIdx.x < VR_ESL_VOLUME_DIMS) {
+		const uint32_t e = zb * VR_ESL_VOLUME_DIMS * VR_ESL_VOLUME_DIMS + yb * VR_ESL_VOLUME_DIMS + threadIdx.x;
+		minmax[2 * e] = (uint8_t) smin[threadIdx.x];
+		minmax[2 * e + 1] = (uint8_t) smax[threadIdx.x];
+	}
+}
+
+__global__ void minmax_init_kernel(uint8_t *minmax) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < 32u * 32u * 32u) { minmax[2 * i] = 255; minmax[2 * i + 1] = 0; }   // RaycasterBase.cpp:101-104
+}
+
+hipError_t launch_minmax(const void *volume, uint32_t bpv, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                         uint32_t bd, uint8_t *minmax_dev, hipStream_t stream) {
+	hipLaunchKernelGGL(minmax_init_kernel, dim3(128), dim3(256), 0, stream, minmax_dev);
+	const dim3 grid((dim_y + bd - 1) / bd, (dim_z + bd - 1) / bd);
+	if (bpv == 1) hipLaunchKernelGGL(minmax_kernel<1>, grid, dim3(256), 0, stream, volume, dim_x, dim_y, dim_z, bd, minmax_dev);
+	else          hipLaunchKernelGGL(minmax_kernel<2>, grid, dim3(256), 0, stream, volume, dim_x, dim_y, dim_z, bd, minmax_dev);
+	return hipGetLastError();
+}
+
+// ---- feeders: 256-bin histogram (ModelBase.cpp:19-26) ----------------------------------------------------------------------
+
+template <int BPV>
+__global__ __launch_bounds__(256)
+void histogram_kernel(const void *__restrict__ vol, uint64_t voxels, unsigned long long *__restrict__ hist) {
+	__shared__ uint32_t sh[4][256];                      // one sub-histogram per wave: fewer same-address LDS atomics
+	for (uint32_t i = threadIdx.x; i < 1024; i += 256) ((uint32_t *) sh)[i] = 0;
+	__syncthreads();
+	uint32_t *mine = sh[threadIdx.x >> 6];
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	const uint64_t vec = voxels * BPV / 16;              // whole 16-byte chunks
+	for (uint64_t c = (uint64_t) blockIdx.x * 256 + threadIdx.x; c < vec; c += stride) {
+		const uint4 v = ((const uint4 *) vol)[c];
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+		#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			if (BPV == 1) {
+				atomicAdd(&mine[w[i] & 0xffu], 1u); atomicAdd(&mine[(w[i] >> 8) & 0xffu], 1u);
+				atomicAdd(&mine[(w[i] >> 16) & 0xffu], 1u); atomicAdd(&mine[w[i] >> 24], 1u);
+			} else {
+				atomicAdd(&mine[(w[i] >> 8) & 0xffu], 1u); atomicAdd(&mine[w[i] >> 24], 1u);
+			}
+		}
+	}
+	// tail (fewer than 16 bytes)
+	if (blockIdx.x == 0) {
+		const uint64_t done = vec * 16 / BPV;
+		for (uint64_t i = done + threadIdx.x; i < voxels; i += 256) {
+			const uint32_t s = BPV == 1 ? ((const uint8_t *) vol)[i] : (uint32_t) (((const uint16_t *) vol)[i] >> 8);
+			atomicAdd(&mine[s], 1u);
+		}
+	}
+	__syncthreads();
+	const uint32_t b = threadIdx.x;
+	const unsigned long long sum = (unsigned long long) sh[0][b] + sh[1][b] + sh[2][b] + sh[3][b];
+	if (sum) atomicAdd(&hist[b], sum);
+}
+
+hipError_t launch_histogram(const void *volume, uint32_t bpv, uint64_t voxels, unsigned long long *hist, hipStream_t stream) {
+	hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long), stream);
+	if (e != hipSuccess) return e;
+	// each workgroup may add at most 2^32-1 per bin into its LDS counters: bound the voxels per workgroup
+	uint64_t blocks = (voxels + (1ull << 24) - 1) >> 24;
+	if (blocks < 2048) blocks = 2048;
+	if (bpv == 1) hipLaunchKernelGGL(histogram_kernel<1>, dim3((uint32_t) blocks), dim3(256), 0, stream, volume, voxels, hist);
+	else          hipLaunchKernelGGL(histogram_kernel<2>, dim3((uint32_t) blocks), dim3(256), 0, stream, volume, voxels, hist);
+	return hipGetLastError();
+}
+
+// ---- synthetic benchmark volumes, integer-only, generated straight into HBM --------------------------------
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+	h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+	return h;
+}
+
+template <int BPV>
+__global__ __launch_bounds__(256)
+void generate_kernel(void *__restrict__ vol, uint32_t kind, uint32_t n, uint32_t seed) {
+	const long long N = n;
+	const uint64_t total = (uint64_t) n * n * n;
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	for (uint64_t idx = (uint64_t) blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+		const uint32_t h = fmix32((uint32_t) (idx ^ (idx >> 32)) + seed * 0x9E3779B9u);
+		uint32_t v;
+		if (kind == 0) {
+			const long long x = (long long) (idx % n), y = (long long) ((idx / n) % n), z = (long long) (idx / ((uint64_t) n * n));
+			const long long ax = 2 * x + 1 - N, ay = 2 * y + 1 - N, az = 2 * z + 1 - N;
+			const long long d2 = ax * ax + ay * ay + az * az;
+			long long t = 1000 * d2 / (N * N) - 360;
+			if (t < 0) t = -t;
+			long long shell = 255 - t * 255 / 240;
+			if (shell < 0) shell = 0;
+			v = (uint32_t) shell + (h & 15u);
+			if (v > 255u) v = 255u;
+		} else {
+			v = h & 255u;
+		}
+		if (BPV == 1) ((uint8_t *) vol)[idx] = (uint8_t) v; else ((uint16_t *) vol)[idx] = (uint16_t) (v * 257u);
+	}
+}
+
+hipError_t launch_generate(void *volume, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bpv, hipStream_t stream) {
+	if (bpv == 1) hipLaunchKernelGGL(generate_kernel<1>, dim3(8192), dim3(256), 0, stream, volume, kind, n, seed);
+	else          hipLaunchKernelGGL(generate_kernel<2>, dim3(8192), dim3(256), 0, stream, volume, kind, n, seed);
+	return hipGetLastError();
+}
+
+}  // namespace vr

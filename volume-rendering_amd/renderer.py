@@ -1,0 +1,122 @@
+"""HipRenderer — python face of the C ABI context (include/vr_hip.h); method names follow the reference's Renderer
+interface (VolumeRendering/Renderer.h:13-28)."""
+import ctypes as C
+
+import numpy as np
+
+from .binding import VrError, VrParams, VrTiming, lib
+
+
+class HipRenderer:
+    def __init__(self, device=0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.vr_hip_create(int(device), C.byref(self._ctx))
+        if rc:
+            msg = self._L.vr_hip_last_error(self._ctx).decode() if self._ctx else "no usable HIP device; there is no CPU fallback"
+            if self._ctx:
+                self._L.vr_hip_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise VrError(rc, msg)
+        self.device = int(device)
+        self.dims = None
+        self.bytes_per_voxel = None
+
+    # -- lifetime
+    def close(self):
+        if self._ctx:
+            self._L.vr_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise VrError(rc, f"{what}: {self._L.vr_hip_last_error(self._ctx).decode()}")
+
+    def get_name(self):
+        return "HIP MI355X"
+
+    # -- Renderer::set_*
+    def set_window_buffer(self, width, height):
+        self._check(self._L.vr_hip_set_window(self._ctx, width, height), "set_window_buffer")
+
+    def set_transfer_fn(self, tf_premult, esl_bits):
+        tf = np.ascontiguousarray(tf_premult, dtype=np.float32)
+        esl = np.ascontiguousarray(esl_bits, dtype=np.uint32)
+        if tf.size != 512 or esl.size != 1024:
+            raise VrError(1, "transfer_fn must be 128x4 floats and esl 1024 words")
+        self._check(self._L.vr_hip_set_transfer_fn(self._ctx, tf.ctypes.data, esl.ctypes.data), "set_transfer_fn")
+
+    def set_volume(self, voxels):
+        """voxels: numpy array shaped (z, y, x), uint8 or uint16."""
+        v = np.ascontiguousarray(voxels)
+        if v.dtype not in (np.uint8, np.uint16) or v.ndim != 3:
+            raise VrError(1, "volume must be a 3-D uint8 / uint16 array")
+        z, y, x = v.shape
+        self._check(self._L.vr_hip_set_volume(self._ctx, v.ctypes.data, x, y, z, v.dtype.itemsize), "set_volume")
+        self.dims, self.bytes_per_voxel = (x, y, z), v.dtype.itemsize
+
+    def set_volume_device(self, dev_ptr, dims, bytes_per_voxel):
+        self._check(self._L.vr_hip_set_volume_device(self._ctx, C.c_void_p(dev_ptr), dims[0], dims[1], dims[2], bytes_per_voxel),
+                    "set_volume_device")
+        self.dims, self.bytes_per_voxel = tuple(dims), bytes_per_voxel
+
+    def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
+        """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
+        k = {"shell": 0, "noise": 1}[kind]
+        self._check(self._L.vr_hip_generate_volume(self._ctx, k, n, seed, bytes_per_voxel), "generate_volume")
+        self.dims, self.bytes_per_voxel = (n, n, n), bytes_per_voxel
+
+    def download_volume(self):
+        x, y, z = self.dims
+        out = np.empty((z, y, x), dtype=np.uint8 if self.bytes_per_voxel == 1 else np.uint16)
+        self._check(self._L.vr_hip_download_volume(self._ctx, out.ctypes.data, out.nbytes), "download_volume")
+        return out
+
+    # -- Renderer::render_volume
+    def render_volume(self, params):
+        """Host-buffer flavour (reference renderer ids 0-2): returns an (out_rows, out_width, 4) uint8 array."""
+        out = np.empty((params.out_rows, params.out_width, 4), dtype=np.uint8)
+        self._check(self._L.vr_hip_render(self._ctx, C.byref(params), out.ctypes.data), "render_volume")
+        return out
+
+    def render_volume_device(self, params, dev_ptr, stream=None):
+        """Device-buffer flavour (ids 3-4): asynchronous launch into `dev_ptr` on `stream` (raw hipStream_t or None)."""
+        self._check(self._L.vr_hip_render_device(self._ctx, C.byref(params), C.c_void_p(dev_ptr),
+                                                 C.c_void_p(stream) if stream else None), "render_volume_device")
+
+    # -- timing (Profiler.cpp:46-67)
+    def timing(self):
+        t = VrTiming()
+        self._check(self._L.vr_hip_timing(self._ctx, C.byref(t)), "timing")
+        return t
+
+    def timing_reset(self):
+        self._check(self._L.vr_hip_timing_reset(self._ctx), "timing_reset")
+
+    # -- feeders on the GPU
+    def volume_minmax(self):
+        mm = np.empty((32 * 32 * 32, 2), dtype=np.uint8)
+        bd = C.c_uint32()
+        bs = (C.c_float * 3)()
+        ms = C.c_float()
+        self._check(self._L.vr_hip_volume_minmax(self._ctx, mm.ctypes.data, C.byref(bd), bs, C.byref(ms)), "volume_minmax")
+        return mm, int(bd.value), tuple(float(v) for v in bs), float(ms.value)
+
+    def volume_histogram(self):
+        h = np.empty(256, dtype=np.uint64)
+        ms = C.c_float()
+        self._check(self._L.vr_hip_volume_histogram(self._ctx, h.ctypes.data, C.byref(ms)), "volume_histogram")
+        return h, float(ms.value)
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_uint32()
+        mem = C.c_uint64()
+        self._check(self._L.vr_hip_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)), "device_info")
+        return name.value.decode(), int(cus.value), int(mem.value)
