@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-view kernel timings of the ray-march kernel (hipEvents inside libvr_hip.so).  Tuning aid, run on the GPU box:
+    python scripts/perf_probe.py --volume 1024 --viewport 2048 --views 0,1,2,3,4,5,6,7 --mode nooptims --sampling trilinear
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--volume", type=int, default=1024)
+    ap.add_argument("--viewport", type=int, default=2048)
+    ap.add_argument("--views", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--mode", default="nooptims")
+    ap.add_argument("--sampling", default="trilinear")
+    ap.add_argument("--kind", default="shell")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--light", type=float, default=0.6)
+    a = ap.parse_args()
+    vr = importlib.import_module("volume-rendering_amd")
+    r = vr.HipRenderer(0)
+    n, W = a.volume, a.viewport
+    r.generate_volume(a.kind, n, seed=1)
+    mm, _, _, ms = r.volume_minmax()
+    scene = vr.Scene().set_volume(dims=(n, n, n), minmax=mm)
+    if a.mode == "nooptims":
+        scene.set_modes(esl=False, ray_threshold=1.0)
+    scene.set_modes(light_kd=a.light)
+    r.set_transfer_fn(scene.tf, scene.esl)
+    samp = vr.SAMPLE_TRILINEAR if a.sampling == "trilinear" else vr.SAMPLE_NEAREST
+    buf = torch.empty((W, W, 4), dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for v in [int(x) for x in a.views.split(",")]:
+        p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
+        r.render_volume_device(p, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        r.timing_reset()
+        for _ in range(a.reps):
+            r.render_volume_device(p, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t = r.timing()
+        res[v] = round(t.kernel_ms_sum / t.launches, 4)
+    print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "light": a.light,
+                      "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4)}))
+
+
+if __name__ == "__main__":
+    main()

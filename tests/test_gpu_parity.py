@@ -1,0 +1,214 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against (a) frames rendered by the reference's own
+CPURenderer (tests/golden) and (b) the CPU oracle on the same inputs.
+
+Bar: NEAREST mode bit-exact (integer RGBA8 output of identical fp32 arithmetic); TRILINEAR mode bit-exact against the
+oracle's restatement of GPURenderer4's texture semantics (tolerance in the test: 0)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import compare_frames, fnv1a32
+
+pytestmark = pytest.mark.gpu
+
+
+def load_volume(gpu, golden, name):
+    st = golden.volume_state(name)
+    gpu.set_transfer_fn(st["tf"], st["esl"])
+    gpu.set_volume(golden.voxels(name))
+    return st
+
+
+def test_native_library_is_the_one_loaded(vr, gpu):
+    with open("/proc/self/maps") as f:
+        assert "libvr_hip.so" in f.read()
+    name, cus, mem = gpu.device_info()
+    assert "gfx950" in name and cus == 256, (name, cus)
+
+
+def test_nearest_bit_exact_vs_reference_frames(vr, gpu, golden):
+    """Every golden frame (Bucky 8 benchmark views default/no-optims at 256^2 and 64^2, odd windows, camera inside the
+    cube, light off, ray-step limits, synthetic shell, non-cubic volume with an edited TF) — NEAREST, bit for bit."""
+    gpu.set_window_buffer(256, 256)
+    current = None
+    for case in golden.cases(with_frames_only=True):
+        if case["volume"] != current:
+            load_volume(gpu, golden, case["volume"])
+            current = case["volume"]
+        out = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+        ndiff, maxd = compare_frames(out, golden.frame(case))
+        assert ndiff == 0, f"{case['label']}: {ndiff} pixels differ, max delta {maxd}"
+
+
+def test_config2_shell256_hashes(vr, gpu, golden):
+    """BASELINE config 2: shell 256^3 generated on the GPU, 1024x1024, ortho poses 0/1, default and no-optims."""
+    gpu.generate_volume("shell", 256, seed=1)
+    assert fnv1a32(gpu.download_volume()) == "6d5baf38"
+    st = golden.volume_state("shell256")
+    gpu.set_transfer_fn(st["tf"], st["esl"])
+    gpu.set_window_buffer(1024, 1024)
+    for case in golden.cases():
+        if case["volume"] != "shell256":
+            continue
+        out = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+        assert fnv1a32(out) == case["frame_fnv1a32"], case["label"]
+        assert int((out[..., 3] != 0).sum()) == case["nonzero_alpha"]
+
+
+def test_trilinear_bit_exact_vs_oracle(vr, gpu, golden, oracle):
+    gpu.set_window_buffer(256, 256)
+    current, checked = None, 0
+    for case in golden.cases(with_frames_only=True):
+        if "bench256" in case["label"] and "view1" not in case["label"] and "view6" not in case["label"]:
+            continue                                            # keep the CPU side of this test short
+        if case["volume"] != current:
+            st = load_volume(gpu, golden, case["volume"])
+            current = case["volume"]
+        p = golden.params(case, vr.SAMPLE_TRILINEAR)
+        out = gpu.render_volume(p)
+        ref = oracle.render(p, golden.voxels(case["volume"]), st["tf"], st["esl"], threads=16)
+        ndiff, maxd = compare_frames(out, ref)
+        assert ndiff == 0, f"{case['label']}: {ndiff} pixels differ, max delta {maxd}"
+        checked += 1
+    assert checked >= 30
+
+
+def test_u16_volume_matches_oracle(vr, gpu, golden, oracle):
+    """Build-side extension (the reference quantises 16-bit data to 8 bit on load, ModelBase.cpp:95-98)."""
+    vox16 = golden.voxels("bucky").astype(np.uint16) * 257
+    st = golden.volume_state("bucky")
+    gpu.set_transfer_fn(st["tf"], st["esl"])
+    gpu.set_volume(vox16)
+    gpu.set_window_buffer(96, 96)
+    for label in ("nolight_view1", "nolight_view5", "bench64_view3_default", "bench64_view6_default"):
+        case = [c for c in golden.cases(True) if c["label"] == label][0]
+        for mode in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+            p = golden.params(case, mode)
+            out = gpu.render_volume(p)
+            ref = oracle.render(p, vox16, st["tf"], st["esl"])
+            assert compare_frames(out, ref) == (0, 0), (label, mode)
+    # u8 * 257 in NEAREST mode is the same picture as the u8 volume except for the /65535 vs /255 shading scale
+    case = [c for c in golden.cases(True) if c["label"] == "nolight_view1"][0]
+    out16 = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+    assert np.array_equal(out16, golden.frame(case))
+
+
+def test_partition_concatenates_to_the_whole_frame(vr, gpu, golden):
+    """SURVEY §8e correctness check: n ranks' bands assembled == 1-rank frame, byte for byte."""
+    from importlib import import_module
+    dist_mod = import_module("volume-rendering_amd.distributed")
+    import torch
+    load_volume(gpu, golden, "bucky")
+    gpu.set_window_buffer(199, 178)
+    case = [c for c in golden.cases(True) if c["label"] == "window_199x178_view1"][0]
+    for mode in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+        whole = gpu.render_volume(golden.params(case, mode))
+        for world, band in ((2, 16), (3, 16), (4, 8), (2, 89), (8, 16), (5, 7)):
+            parts = []
+            for rank in range(world):
+                split = dist_mod.FrameSplit(199, 178, world, rank, band)
+                parts.append(torch.from_numpy(gpu.render_volume(split.apply(golden.params(case, mode)))))
+            frame = split.assemble(torch.stack(parts)).numpy()
+            assert np.array_equal(frame, whole), (mode, world, band)
+    # a column window (x0 / out_width) of the frame
+    whole = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+    p = golden.params(case, vr.SAMPLE_NEAREST)
+    p.x0, p.out_width = 50, 64
+    assert np.array_equal(gpu.render_volume(p), whole[:, 50:114])
+
+
+def test_device_buffer_path_with_torch_stream(vr, gpu, golden):
+    """vr_hip_render_device into a torch tensor on torch's current stream == the host-buffer path."""
+    import torch
+    load_volume(gpu, golden, "bucky")
+    gpu.set_window_buffer(256, 256)
+    case = [c for c in golden.cases(True) if c["label"] == "bench256_view5_default"][0]
+    p = golden.params(case, vr.SAMPLE_NEAREST)
+    dev = torch.full((256, 256, 4), 77, dtype=torch.uint8, device="cuda:0")     # the kernel must overwrite every byte
+    gpu.render_volume_device(p, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), golden.frame(case))
+    t = gpu.timing()
+    assert t.launches >= 1 and t.kernel_ms > 0
+
+
+def test_cpp_renderer_mirror(vr, gpu, golden):
+    """The host C++ mirror: RaycasterBase::reset_transfer_fn/set_volume -> HipRenderer(raycaster).render_volume()."""
+    vox = golden.voxels("bucky")
+    scene = vr.Scene().set_volume(voxels=vox)
+    st = golden.volume_state("bucky")
+    assert np.array_equal(scene.tf, st["tf"]) and np.array_equal(scene.esl, st["esl"])
+    for label in ("bench256_view2_default", "bench256_view7_default"):
+        case = [c for c in golden.cases(True) if c["label"] == label][0]
+        p = golden.params(case)
+        out = np.zeros((256, 256, 4), np.uint8)
+        rc = vr.lib().vr_host_render_frame(0, vr.SAMPLE_NEAREST, C.byref(p.view), out.ctypes.data)
+        assert rc == 0
+        assert np.array_equal(out, golden.frame(case)), label
+
+
+def test_error_conventions(vr, golden):
+    """0 ok / non-zero failure, never exit (reference: CPURenderer.cpp:44-45, GPURenderer1.cu:91-95,101-102)."""
+    L = vr.lib()
+    r = vr.HipRenderer(0)
+    case = golden.cases(True)[0]
+    p = golden.params(case)
+    buf = np.zeros((p.out_rows, p.out_width, 4), np.uint8)
+    assert L.vr_hip_render(r._ctx, C.byref(p), buf.ctypes.data) == 5           # VR_ERR_NOT_READY: nothing set yet
+    assert L.vr_hip_set_volume(r._ctx, None, 32, 32, 32, 1) == 1               # NULL data -> 1 like the reference
+    assert L.vr_hip_set_volume(r._ctx, buf.ctypes.data, 0, 32, 32, 1) == 1
+    assert L.vr_hip_set_volume(r._ctx, buf.ctypes.data, 32, 32, 32, 3) == 1
+    assert L.vr_hip_set_transfer_fn(r._ctx, None, None) == 1
+    st = golden.volume_state("bucky")
+    r.set_transfer_fn(st["tf"], st["esl"])
+    r.set_volume(golden.voxels("bucky"))
+    assert L.vr_hip_render(r._ctx, C.byref(p), None) == 1                      # NULL buffer -> 1
+    assert L.vr_hip_render(r._ctx, None, buf.ctypes.data) == 1
+    assert L.vr_hip_render(r._ctx, C.byref(p), buf.ctypes.data) == 5           # window buffer not set
+    r.set_window_buffer(p.view.width, p.view.height)
+    bad = p.copy(); bad.ray_step = 0.0
+    assert L.vr_hip_render(r._ctx, C.byref(bad), buf.ctypes.data) == 1         # would never terminate
+    bad = p.copy(); bad.view.origin[0] = float("nan")
+    assert L.vr_hip_render(r._ctx, C.byref(bad), buf.ctypes.data) == 1
+    bad = p.copy(); bad.sampling = 9
+    assert L.vr_hip_render(r._ctx, C.byref(bad), buf.ctypes.data) == 1
+    bad = p.copy(); bad.band_rows = 0
+    assert L.vr_hip_render(r._ctx, C.byref(bad), buf.ctypes.data) == 1
+    assert b"band" in L.vr_hip_last_error(r._ctx)
+    assert L.vr_hip_render(r._ctx, C.byref(p), buf.ctypes.data) == 0           # and the context still works
+    assert np.array_equal(buf, golden.frame(case))
+    ctx = C.c_void_p()
+    assert L.vr_hip_create(99, C.byref(ctx)) == 2                              # VR_ERR_NO_DEVICE
+    r.close()
+
+
+def test_feeders_minmax_histogram_generate(vr, gpu, golden, oracle):
+    """GPU feeders against the CPU restatement of RaycasterBase::set_volume / compute_histogram."""
+    for name in ("bucky", "blob_40x24x56", "shell48"):
+        vox = golden.voxels(name)
+        gpu.set_volume(vox)
+        mm, bd, bs, _ = gpu.volume_minmax()
+        omm, obd, obs = oracle.volume_minmax(vox)
+        assert bd == obd and np.array_equal(np.array(bs, np.float32), obs)
+        assert np.array_equal(mm, omm), name
+        h, _ = gpu.volume_histogram()
+        assert np.array_equal(h, oracle.histogram(vox)), name
+        # TF/ESL built by the host mirror from the GPU min/max == what the reference built (golden)
+        st = golden.volume_state(name)
+        scene = vr.Scene().set_volume(dims=(vox.shape[2], vox.shape[1], vox.shape[0]), minmax=mm)
+        if st["base_tf"] is not None:
+            scene.set_base_transfer_fn(st["base_tf"])
+        assert np.array_equal(scene.esl, st["esl"]) and np.array_equal(scene.tf, st["tf"]), name
+        assert scene.params.esl_block_dims == st["esl_block_dims"]
+        assert np.float32(scene.params.ray_step) == st["ray_step"]
+    # streaming (16-byte) path of the reduction: 512^3 -> block 16; u16 too
+    for n, bpv, kind in ((512, 1, "shell"), (256, 2, "noise"), (320, 1, "noise")):
+        gpu.generate_volume(kind, n, seed=3, bytes_per_voxel=bpv)
+        vox = gpu.download_volume()
+        assert np.array_equal(vox, oracle.generate_volume(kind, n, 3, bpv)), (n, bpv, kind)
+        mm, bd, bs, _ = gpu.volume_minmax()
+        omm, obd, obs = oracle.volume_minmax(vox)
+        assert bd == obd and np.array_equal(mm, omm), (n, bpv, kind)
+        h, _ = gpu.volume_histogram()
+        assert np.array_equal(h, oracle.histogram(vox))

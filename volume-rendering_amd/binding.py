@@ -55,6 +55,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Loaded first, the
+    # dynamic linker resolves libvr_hip.so's dependency on that SONAME to the SAME object, so device pointers, streams
+    # and events are shared with torch.  Loaded the other way round the process ends up with two runtimes and the
+    # second one finds no device.
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing — build it with `make -C volume-rendering_amd/csrc` "
