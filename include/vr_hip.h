@@ -48,6 +48,16 @@ typedef enum vr_sampling {
 	                             normalised coordinates + clamp addressing, linearly filtered transfer function */
 } vr_sampling;
 
+/* How the TRILINEAR path keeps the volume in HBM (NEAREST always reads the reference's linear array).
+ * Both layouts give bit-identical images; the choice is speed only. */
+typedef enum vr_layout {
+	VR_LAYOUT_LINEAR  = 0,    /* x-fastest linear array exactly as Model::data (ModelBase.h:18-22) */
+	VR_LAYOUT_BRICKED = 1     /* default: "quad bricks" — every element packs the 2x2 (x,y) voxel neighbourhood of a slice into
+	                             one aligned word, stored in 8x8x(8+1)-element bricks: a trilinear sample is two aligned loads
+	                             from one brick and the cache-line footprint no longer depends on the view direction
+	                             (4.5x the voxel bytes in HBM; volume-rendering_amd/csrc/vr_device.h) */
+} vr_layout;
+
 /* struct View, ViewBase.h:14-21 (dims widened to 32 bit, bool -> uint32) */
 typedef struct vr_view {
 	uint32_t width, height;     /* View::dims */
@@ -110,6 +120,10 @@ int vr_hip_set_volume(vr_ctx *ctx, const void *host_voxels, uint32_t dim_x, uint
 /* same, source already in device memory (x-fastest, unpadded) */
 int vr_hip_set_volume_device(vr_ctx *ctx, const void *dev_voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                              uint32_t bytes_per_voxel);
+
+/* Layout policy for the TRILINEAR copy of the volume (default VR_LAYOUT_BRICKED).  Takes effect immediately for the
+ * resident volume (rebuilds or drops the bricked copy) and for later set_volume calls.  No reference counterpart. */
+int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
 
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,

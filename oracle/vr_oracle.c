@@ -77,9 +77,9 @@ static inline uint32_t sample_nearest(const scene *s, f3 pos) {
  * full fp32 precision, the texture unit would quantise it to 8 fractional bits.
  *
  * TRILINEAR-mode arithmetic is DEFINED here with explicit fused multiply-adds (the GPU the reference's renderer 4
- * ran on contracts to FMA as well; no CPU run of it exists): with f = (pos+1)/2,
- *     xB = f*N - 0.5 = fma(pos, N/2, N/2 - 0.5).
- * The HIP kernel executes the same fmaf sequence, so the two agree bit for bit. */
+ * ran on contracts to FMA as well; no CPU run of it exists).  With f = (pos+1)/2 and pos = origin + dir*k:
+ *     xB = f*N - 0.5 = pos*(N/2) + (N/2 - 0.5) = k * (dir*N/2) + fma(origin, N/2, N/2 - 0.5) = fma(k, A, B),
+ * A and B computed once per ray.  The HIP kernel executes the same fmaf sequence, so the two agree bit for bit. */
 static inline void axis_setup(float xb, uint32_t n, uint32_t *i0, uint32_t *i1, float *a) {
 	float fl = floorf(xb);
 	*a = xb - fl;
@@ -92,13 +92,14 @@ static inline void axis_setup(float xb, uint32_t n, uint32_t *i0, uint32_t *i1, 
 
 static inline float lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
 
-/* trilinear fetch, result normalised to [0,1] like cudaReadModeNormalizedFloat (VR/GPURenderer4.cu:12) */
-static inline float sample_trilinear(const scene *s, f3 pos) {
+/* trilinear fetch at texel-space coordinates (xb,yb,zb); returns the interpolated RAW voxel value (0..255 or
+ * 0..65535) — the normalisation of cudaReadModeNormalizedFloat (VR/GPURenderer4.cu:12) is folded into the constants
+ * of its two consumers (transfer-function coordinate, shading difference). */
+static inline float sample_trilinear_raw(const scene *s, float xb, float yb, float zb) {
 	uint32_t x0, x1, y0, y1, z0, z1; float ax, ay, az;
-	float hx = 0.5f * (float) s->dx, hy = 0.5f * (float) s->dy, hz = 0.5f * (float) s->dz;
-	axis_setup(fmaf(pos.x, hx, hx - 0.5f), s->dx, &x0, &x1, &ax);
-	axis_setup(fmaf(pos.y, hy, hy - 0.5f), s->dy, &y0, &y1, &ay);
-	axis_setup(fmaf(pos.z, hz, hz - 0.5f), s->dz, &z0, &z1, &az);
+	axis_setup(xb, s->dx, &x0, &x1, &ax);
+	axis_setup(yb, s->dy, &y0, &y1, &ay);
+	axis_setup(zb, s->dz, &z0, &z1, &az);
 	float v000 = (float) fetch_raw(s, x0, y0, z0), v100 = (float) fetch_raw(s, x1, y0, z0);
 	float v010 = (float) fetch_raw(s, x0, y1, z0), v110 = (float) fetch_raw(s, x1, y1, z0);
 	float v001 = (float) fetch_raw(s, x0, y0, z1), v101 = (float) fetch_raw(s, x1, y0, z1);
@@ -106,18 +107,33 @@ static inline float sample_trilinear(const scene *s, f3 pos) {
 	float c00 = lerp(v000, v100, ax), c10 = lerp(v010, v110, ax);
 	float c01 = lerp(v001, v101, ax), c11 = lerp(v011, v111, ax);
 	float c0 = lerp(c00, c10, ay), c1 = lerp(c01, c11, ay);
-	float c = lerp(c0, c1, az);
-	return c * (s->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
+	return lerp(c0, c1, az);
 }
 
-/* linearly filtered TF fetch: tex1D(transfer_fn_texture, sample), VR/GPURenderer4.cu:77,91-99
- * (normalised coordinate, clamp): xB = s*128 - 0.5 */
-static inline f4 tf_linear(const scene *s, float sample) {
+/* linearly filtered TF fetch: tex1D(transfer_fn_texture, sample), VR/GPURenderer4.cu:77,91-99 (normalised
+ * coordinate, clamp): xB = sample*128 - 0.5 with sample = raw/255  ==>  xB = fma(raw, 128/255, -0.5) */
+static inline f4 tf_linear(const scene *s, float raw) {
 	uint32_t i0, i1; float a;
-	axis_setup(fmaf(sample, (float) VR_TF_SIZE, -0.5f), VR_TF_SIZE, &i0, &i1, &a);
+	const float scale = s->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
+	axis_setup(fmaf(raw, scale, -0.5f), VR_TF_SIZE, &i0, &i1, &a);
 	f4 c0 = s->tf[i0], c1 = s->tf[i1];
 	f4 r = { lerp(c0.x, c1.x, a), lerp(c0.y, c1.y, a), lerp(c0.z, c1.z, a), lerp(c0.w, c1.w, a) };
 	return r;
+}
+
+/* 1/sqrt(x) of the TRILINEAR-mode light vector: integer seed + three Newton steps, every operation a plain IEEE
+ * fp32 op so that CPU and GPU agree bit for bit (relative error < 2e-7; the result only offsets the shading sample by
+ * 0.01 units along the light direction, VR/GPURenderer4.cu:41-47). */
+static inline float rsqrt_nr(float x) {
+	union { float f; uint32_t u; } v;
+	v.f = x;
+	v.u = 0x5f3759dfu - (v.u >> 1);
+	float y = v.f;
+	const float h = 0.5f * x;
+	y = y * fmaf(-(h * y), y, 1.5f);
+	y = y * fmaf(-(h * y), y, 1.5f);
+	y = y * fmaf(-(h * y), y, 1.5f);
+	return y;
 }
 
 /* VR/ViewBase.h:23-35 View::get_ray */
@@ -224,6 +240,10 @@ static void render_ray(const scene *s, int px, int py, uint8_t *out_px, counters
 	if (kx > ky)
 		return;
 	f4 acc = { 0, 0, 0, 0 };
+	const f3 half = f3_make(0.5f * (float) s->dx, 0.5f * (float) s->dy, 0.5f * (float) s->dz);
+	const f3 A = f3_make(direction.x * half.x, direction.y * half.y, direction.z * half.z);
+	const f3 B = f3_make(fmaf(origin.x, half.x, half.x - 0.5f), fmaf(origin.y, half.y, half.y - 0.5f),
+	                     fmaf(origin.z, half.z, half.z - 0.5f));
 	f3 light_pos = f3_make(p->view.light_pos[0], p->view.light_pos[1], p->view.light_pos[2]);
 	const float raw_scale = s->bpv == 1 ? 255.0f : 65535.0f;
 	while (kx <= ky) {                                   /* colour accumulation loop */
@@ -241,15 +261,18 @@ static void render_ray(const scene *s, int px, int py, uint8_t *out_px, counters
 				c->shade_fetches++;
 			}
 		} else {
-			float sample = sample_trilinear(s, pt);
-			cur = tf_linear(s, sample);
-			if (cur.w > 0.05f && p->light_kd > 0.01f) {  /* VR/GPURenderer4.cu:41-51 shade_texture */
+			const float xb = fmaf(kx, A.x, B.x), yb = fmaf(kx, A.y, B.y), zb = fmaf(kx, A.z, B.z);
+			float raw = sample_trilinear_raw(s, xb, yb, zb);  /* VR/GPURenderer4.cu:76 */
+			cur = tf_linear(s, raw);                           /* VR/GPURenderer4.cu:77 */
+			if (cur.w > 0.05f && p->light_kd > 0.01f) {        /* VR/GPURenderer4.cu:41-51 shade_texture */
 				f3 d = f3_sub(light_pos, pt);
-				float inv = 1.0f / sqrtf(fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x)));
+				float inv = rsqrt_nr(fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x)));
 				f3 light_dir = f3_scale(d, inv);
-				f3 ps = f3_make(fmaf(light_dir.x, 0.01f, pt.x), fmaf(light_dir.y, 0.01f, pt.y), fmaf(light_dir.z, 0.01f, pt.z));
-				float sample_l = sample_trilinear(s, ps);
-				float diffuse = (sample_l - sample) * p->light_kd;
+				/* texel coordinate of pos + 0.01*light_dir = xB + light_dir * (0.01 * N/2) */
+				float raw_l = sample_trilinear_raw(s, fmaf(light_dir.x, 0.01f * half.x, xb),
+				                                      fmaf(light_dir.y, 0.01f * half.y, yb),
+				                                      fmaf(light_dir.z, 0.01f * half.z, zb));
+				float diffuse = (raw_l - raw) * (p->light_kd * (s->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f)));
 				cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				c->shade_fetches++;
 			}

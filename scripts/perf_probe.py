@@ -23,9 +23,11 @@ def main():
     ap.add_argument("--kind", default="shell")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--light", type=float, default=0.6)
+    ap.add_argument("--layout", default="bricked")
     a = ap.parse_args()
     vr = importlib.import_module("volume-rendering_amd")
     r = vr.HipRenderer(0)
+    r.set_layout(vr.LAYOUT_BRICKED if a.layout == "bricked" else vr.LAYOUT_LINEAR)
     n, W = a.volume, a.viewport
     r.generate_volume(a.kind, n, seed=1)
     mm, _, _, ms = r.volume_minmax()
@@ -48,7 +50,7 @@ def main():
         torch.cuda.synchronize()
         t = r.timing()
         res[v] = round(t.kernel_ms_sum / t.launches, 4)
-    print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "light": a.light,
+    print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "layout": a.layout, "light": a.light,
                       "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4)}))
 
 

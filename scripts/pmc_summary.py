@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 --pmc CSV output (one dir per pass) per kernel: mean counter value per dispatch."""
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "raymarch"
+for d in sorted(glob.glob(os.path.join(root, "*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        acc = collections.defaultdict(list)
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if pat in row.get("Kernel_Name", ""):
+                    acc[row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+        for k, v in acc.items():
+            per = collections.defaultdict(float)
+            for did, val in v:
+                per[did] += val
+            vals = [per[k2] for k2 in sorted(per)]
+            print(f"{os.path.basename(d):8s} {k:40s} n={len(vals)} last={vals[-1]:.6g} mean={sum(vals)/len(vals):.6g}")

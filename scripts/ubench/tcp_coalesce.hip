@@ -1,0 +1,64 @@
+// Microbenchmark: how does the gfx950 vector L1 (TCP) coalesce a wave64 4-byte gather?
+// Pattern A(n): n adjacent lanes share one 128-byte line (contiguous dwords); Pattern B(n): the lanes that share a line are
+// interleaved (lane l -> line l % (64/n)); Pattern C(n, sector): like B but lanes of a line spread over different 32B sectors.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+__global__ __launch_bounds__(256) void k(const uint8_t *buf, uint32_t *out, int iters, const uint32_t *lane_off) {
+	const int lane = threadIdx.x & 63;
+	uint32_t off = lane_off[lane] + (threadIdx.x >> 6) * 16384 + (blockIdx.x & 7) * 65536;
+	uint32_t acc = 0, walk = 0;
+	for (int i = 0; i < iters; i++) {
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			acc ^= *(const uint32_t *) (buf + off + walk + u * 128 * 1024);
+		}
+		walk = (walk + 8192) & 16383;   // stays inside this wave's 16 KiB window
+	}
+	out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+static void run(const uint8_t *buf, uint32_t *out, uint32_t *d_off, const uint32_t *h_off, const char *what) {
+	hipMemcpy(d_off, h_off, 64 * 4, hipMemcpyHostToDevice);
+	const int iters = 3000, blocks = 256 * 8;
+	k<<<blocks, 256>>>(buf, out, 50, d_off);
+	hipDeviceSynchronize();
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipEventRecord(e0);
+	k<<<blocks, 256>>>(buf, out, iters, d_off);
+	hipEventRecord(e1); hipDeviceSynchronize();
+	float ms; hipEventElapsedTime(&ms, e0, e1);
+	double loads_per_cu = (double) iters * 8 * 4 * 8;
+	printf("%-58s %7.2f ns per wave-load per CU\n", what, ms * 1e6 / loads_per_cu);
+}
+
+int main() {
+	uint8_t *buf; uint32_t *out, *d_off; uint32_t h[64]; char name[128];
+	hipMalloc(&buf, 4 << 20); hipMemset(buf, 1, 4 << 20); hipMalloc(&out, 256 * 2048 * 4); hipMalloc(&d_off, 256);
+	for (int n : {1, 2, 4, 8, 16, 32}) {
+		for (int l = 0; l < 64; l++) h[l] = (l / n) * 128 + (l % n) * 4;
+		snprintf(name, sizeof name, "A: %2d adjacent lanes per line, contiguous dwords", n); run(buf, out, d_off, h, name);
+	}
+	for (int n : {2, 4, 8, 16}) {
+		int nl = 64 / n;
+		for (int l = 0; l < 64; l++) h[l] = (l % nl) * 128 + (l / nl) * 4;
+		snprintf(name, sizeof name, "B: %2d interleaved lanes per line, contiguous dwords", n); run(buf, out, d_off, h, name);
+	}
+	for (int n : {2, 4}) {
+		int nl = 64 / n;
+		for (int l = 0; l < 64; l++) h[l] = (l / n) * 128 + (l % n) * 32;
+		snprintf(name, sizeof name, "C: %2d adjacent lanes per line, one dword per 32B sector", n); run(buf, out, d_off, h, name);
+		(void) nl;
+	}
+	// same dword for pairs / quads of adjacent lanes (2 px per voxel), 16 or 32 distinct dwords, contiguous in ONE line
+	for (int l = 0; l < 64; l++) h[l] = (l / 2) * 4; run(buf, out, d_off, h, "D: lane pairs share a dword, 32 dwords contiguous (1 line)");
+	for (int l = 0; l < 64; l++) h[l] = (l / 4) * 4; run(buf, out, d_off, h, "D: lane quads share a dword, 16 dwords contiguous");
+	// 8x8 pixel tile over a 4x4 element footprint: row r of 8 lanes -> 4 dwords at row stride 32 B (quad-brick slice)
+	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 32 + ((l & 7) / 2) * 4; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, rows 32 B apart (view along z)");
+	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 256 + ((l & 7) / 2) * 4; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, rows 256 B apart");
+	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 256 + ((l & 7) / 2) * 32; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, 32 B and 256 B strides");
+	// all lanes same dword
+	for (int l = 0; l < 64; l++) h[l] = 0; run(buf, out, d_off, h, "F: all lanes one dword");
+	return 0;
+}

@@ -74,6 +74,23 @@ def test_trilinear_bit_exact_vs_oracle(vr, gpu, golden, oracle):
     assert checked >= 30
 
 
+def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
+    """VR_LAYOUT_LINEAR and VR_LAYOUT_BRICKED hold the same voxels: identical images (and both equal the oracle)."""
+    for name, labels in (("bucky", ("bench64_view1_default", "bench64_view6_default", "inside_persp")),
+                         ("blob_40x24x56", ("view1_default", "view7_default", "view3_esl_off"))):   # dims not multiples of 8
+        st = load_volume(gpu, golden, name)
+        gpu.set_window_buffer(256, 256)
+        for label in labels:
+            case = [c for c in golden.cases(True) if c["label"] == label and c["volume"] == name][0]
+            p = golden.params(case, vr.SAMPLE_TRILINEAR)
+            gpu.set_layout(vr.LAYOUT_LINEAR)
+            lin = gpu.render_volume(p)
+            gpu.set_layout(vr.LAYOUT_BRICKED)
+            bri = gpu.render_volume(p)
+            assert np.array_equal(lin, bri), (name, label)
+            assert np.array_equal(bri, oracle.render(p, golden.voxels(name), st["tf"], st["esl"])), (name, label)
+
+
 def test_u16_volume_matches_oracle(vr, gpu, golden, oracle):
     """Build-side extension (the reference quantises 16-bit data to 8 bit on load, ModelBase.cpp:95-98)."""
     vox16 = golden.voxels("bucky").astype(np.uint16) * 257

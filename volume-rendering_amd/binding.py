@@ -4,6 +4,8 @@ import os
 
 SAMPLE_NEAREST = 0      # vr_sampling.VR_SAMPLE_NEAREST   — CPURenderer / GPURenderer1-3 semantics
 SAMPLE_TRILINEAR = 1    # vr_sampling.VR_SAMPLE_TRILINEAR — GPURenderer4 semantics
+LAYOUT_LINEAR = 0        # vr_layout
+LAYOUT_BRICKED = 1
 TF_SIZE = 128
 ESL_VOLUME_SIZE = 1024
 
@@ -76,6 +78,7 @@ def lib():
         "vr_hip_set_transfer_fn": (C.c_int, [vp, vp, vp]),
         "vr_hip_set_volume": (C.c_int, [vp, vp, u32, u32, u32, u32]),
         "vr_hip_set_volume_device": (C.c_int, [vp, vp, u32, u32, u32, u32]),
+        "vr_hip_set_layout": (C.c_int, [vp, u32]),
         "vr_hip_render": (C.c_int, [vp, P(VrParams), vp]),
         "vr_hip_render_device": (C.c_int, [vp, P(VrParams), vp, vp]),
         "vr_hip_timing": (C.c_int, [vp, P(VrTiming)]),

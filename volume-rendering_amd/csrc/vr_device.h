@@ -23,13 +23,50 @@ struct RayKernelArgs {
 	float    half_x, half_y, half_z;   // 0.5f * dim  (TRILINEAR coordinate: xb = fma(pos, half, half - 0.5))
 	float    off_x,  off_y,  off_z;    // 0.5f * dim - 0.5f
 	float    max_x,  max_y,  max_z;    // dim - 1 as float (clamp addressing)
+	float    lh_x,   lh_y,   lh_z;     // 0.01f * half: texel-space length of the shading offset (GPURenderer4.cu:43-46)
+	float    tf_scale;                 // 128/255 (u8) or 128/65535 (u16): raw interpolated voxel -> TF texel coordinate + 0.5
+	float    kd_scaled;                // light_kd / 255 (u8) or / 65535 (u16)
+	uint32_t layout;                   // vr_layout of the TRILINEAR volume
+	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
+
+// TRILINEAR volume layouts.
+//   kLayoutLinear : the reference's x-fastest array (+ zeroed tail slack); a sample = 4 two-voxel loads at VOXEL
+//                   alignment.  Measured on MI355X (scripts/ubench/vmem_rate.hip): a 2-byte load at an odd address costs
+//                   4x an aligned one, and a wave that touches n cache lines pays ~n cycles in the L1 tag pipe.
+//   kLayoutBricked: "quad bricks".  Element (x,y,z) packs the 2x2 (x,y) neighbourhood {v(x,y), v(x+1,y), v(x,y+1),
+//                   v(x+1,y+1)} of slice z (indices clamped at the upper faces, where the weight is exactly 0) into one
+//                   naturally ALIGNED 4-byte (u8) / 8-byte (u16) word.  Elements are stored in bricks of 8x8x8 positions,
+//                   Z-ORDER (Morton) inside the brick: element offset = dilate(z&7) | dilate(x&7) << 1 | dilate(y&7) << 2,
+//                   so every aligned 32-byte sector holds a 2x2x2 block of elements and every 128-byte line a 4x4x2 block.
+//                   A trilinear sample is TWO aligned loads (slices z and z+1); the vector L1 pays about one cycle per
+//                   distinct 32-byte sector a 16-lane group touches (scripts/ubench/tcp_coalesce.hip), and with this
+//                   layout that count no longer depends on the view direction.  Costs 4x the voxel bytes in HBM.
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1 };
+constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
+
+// 3-bit Morton dilation: bit i of v moves to bit 3*i
+__host__ __device__ inline uint32_t dilate3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }
+// element offset inside a brick (z lowest, then x, then y)
+__host__ __device__ inline uint32_t brick_local(uint32_t lx, uint32_t ly, uint32_t lz) {
+	return dilate3(lz) | (dilate3(lx) << 1) | (dilate3(ly) << 2);
+}
 
 // Volume resident in HBM: the reference's linear layout (x fastest, then y, then z — ModelBase.h:18-22) followed by
 // kTailSlack zeroed elements, so the +1 neighbours of a trilinear fetch at the upper faces (weight exactly 0) stay
 // inside the allocation.
 inline uint64_t volume_tail_slack(uint32_t dim_x, uint32_t dim_y) { return (uint64_t) dim_x * dim_y + dim_x + 2; }
 
+// linear -> quad-brick copy
+hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y,
+                           uint32_t dim_z, hipStream_t stream);
+// number of quad elements (each 4 * bytes_per_voxel bytes)
+inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
+	return (uint64_t) ((dim_x + kBrickEdge - 1) / kBrickEdge) * ((dim_y + kBrickEdge - 1) / kBrickEdge) *
+	       ((dim_z + kBrickEdge - 1) / kBrickEdge) * kBrickPitch;
+}
+
+// `volume` is the linear array for NEAREST sampling and for TRILINEAR with kLayoutLinear, the bricked copy otherwise.
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bytes_per_voxel,
                            const float *tf_premult /* 128 x float4 */, const uint32_t *esl_bits /* 1024 */,
                            void *out_rgba, hipStream_t stream);

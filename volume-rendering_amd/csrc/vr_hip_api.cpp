@@ -36,6 +36,8 @@ struct vr_ctx {
 	float *tf = nullptr; uint32_t *esl = nullptr; bool tf_set = false;
 	// volume
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
+	void *vol_bricked = nullptr;            // TRILINEAR copy in the bricked layout (vr_device.h), built by set_volume
+	uint32_t layout = VR_LAYOUT_BRICKED;
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -110,12 +112,19 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.half_x = 0.5f * (float) c->dim[0]; a.half_y = 0.5f * (float) c->dim[1]; a.half_z = 0.5f * (float) c->dim[2];
 	a.off_x = a.half_x - 0.5f; a.off_y = a.half_y - 0.5f; a.off_z = a.half_z - 0.5f;
 	a.max_x = (float) (c->dim[0] - 1); a.max_y = (float) (c->dim[1] - 1); a.max_z = (float) (c->dim[2] - 1);
+	a.lh_x = 0.01f * a.half_x; a.lh_y = 0.01f * a.half_y; a.lh_z = 0.01f * a.half_z;
+	a.tf_scale = c->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
+	a.kd_scaled = p->light_kd * (c->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
+	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
+	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
+	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
+	const void *volume = (p->sampling == VR_SAMPLE_TRILINEAR && c->vol_bricked) ? c->vol_bricked : c->vol;
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
 	VR_TRY(c, hipEventRecord(ev.start, stream));
-	VR_TRY(c, launch_raymarch(a, c->vol, c->bpv, c->tf, c->esl, dev_rgba, stream));
+	VR_TRY(c, launch_raymarch(a, volume, c->bpv, c->tf, c->esl, dev_rgba, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
 	return VR_OK;
@@ -132,11 +141,23 @@ int alloc_volume(vr_ctx *c, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
 		return fail(c, VR_ERR_INVALID, "volume dims out of range (1..65535)");
 	if (bpv != 1 && bpv != 2) return fail(c, VR_ERR_INVALID, "bytes_per_voxel must be 1 or 2");
 	if (c->vol) { (void) hipFree(c->vol); c->vol = nullptr; }
+	if (c->vol_bricked) { (void) hipFree(c->vol_bricked); c->vol_bricked = nullptr; }
 	const uint64_t elems = (uint64_t) x * y * z;
 	const uint64_t slack = volume_tail_slack(x, y);
 	VR_TRY(c, hipMalloc(&c->vol, (elems + slack) * bpv));
 	VR_TRY(c, hipMemsetAsync((uint8_t *) c->vol + elems * bpv, 0, slack * bpv, c->stream));
 	c->vol_elems = elems; c->dim[0] = x; c->dim[1] = y; c->dim[2] = z; c->bpv = bpv;
+	return VR_OK;
+}
+
+// builds (or drops) the bricked TRILINEAR copy of the resident linear volume according to c->layout
+int finalize_volume(vr_ctx *c) {
+	if (c->vol_bricked) { (void) hipFree(c->vol_bricked); c->vol_bricked = nullptr; }
+	if (c->vol == nullptr || c->layout != VR_LAYOUT_BRICKED)
+		return VR_OK;
+	VR_TRY(c, hipMalloc(&c->vol_bricked, bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv));
+	VR_TRY(c, launch_brickify(c->vol, c->vol_bricked, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
 	return VR_OK;
 }
 
@@ -187,6 +208,7 @@ void vr_hip_destroy(vr_ctx *c) {
 	if (c->tf) (void) hipFree(c->tf);
 	if (c->esl) (void) hipFree(c->esl);
 	if (c->vol) (void) hipFree(c->vol);
+	if (c->vol_bricked) (void) hipFree(c->vol_bricked);
 	if (c->minmax) (void) hipFree(c->minmax);
 	if (c->hist) (void) hipFree(c->hist);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -227,7 +249,7 @@ int vr_hip_set_volume(vr_ctx *c, const void *host, uint32_t x, uint32_t y, uint3
 	if (rc) return rc;
 	VR_TRY(c, hipMemcpy(c->vol, host, c->vol_elems * bpv, hipMemcpyHostToDevice));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return VR_OK;
+	return finalize_volume(c);
 }
 
 int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
@@ -238,7 +260,16 @@ int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y,
 	if (rc) return rc;
 	VR_TRY(c, hipMemcpy(c->vol, dev, c->vol_elems * bpv, hipMemcpyDeviceToDevice));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return VR_OK;
+	return finalize_volume(c);
+}
+
+int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (layout != VR_LAYOUT_LINEAR && layout != VR_LAYOUT_BRICKED) return fail(c, VR_ERR_INVALID, "unknown volume layout");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, hipDeviceSynchronize());           // a frame may still be reading the copy we are about to drop
+	c->layout = layout;
+	return finalize_volume(c);
 }
 
 int vr_hip_render_device(vr_ctx *c, const vr_params *p, void *dev_rgba, void *stream) {
@@ -340,7 +371,7 @@ int vr_hip_generate_volume(vr_ctx *c, uint32_t kind, uint32_t n, uint32_t seed, 
 	if (rc) return rc;
 	VR_TRY(c, launch_generate(c->vol, kind, n, seed, bpv, c->stream));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return VR_OK;
+	return finalize_volume(c);
 }
 
 int vr_hip_download_volume(vr_ctx *c, void *host_out, uint64_t bytes) {

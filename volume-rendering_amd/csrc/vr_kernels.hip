@@ -72,56 +72,118 @@ __device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKer
 	return fetch_voxel<BPV, WIDE>(vol, a, ix, iy, iz);
 }
 
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
 __device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
 
-// Two x-adjacent voxels with ONE load: the pair (ix, ix+1) is contiguous in the linear layout.  The address has only
-// voxel alignment (gfx950 global loads accept that); the upper face reads one element into the zeroed tail slack,
-// where the weight is exactly 0.
-template <int BPV>
-__device__ __forceinline__ void load_pair(const void *vol, uint64_t elem, float &v0, float &v1) {
-	if (BPV == 1) {
-		uint16_t w;
-		__builtin_memcpy(&w, (const uint8_t *) vol + elem, 2);
-		v0 = (float) (w & 0xffu); v1 = (float) (w >> 8);
+// ---- manual trilinear fetch, split in two so that the ray-march loop can software-pipeline it -----------------------
+//
+// tri_issue():   texel-space coordinates -> clamp -> cell index + fractions -> address -> ISSUE the loads.
+// tri_resolve(): unpack the returned words and do the 7 lerps.
+// Semantics = tex3D with normalised coordinates, linear filter, clamp addressing (GPURenderer4.cu:76,136-141).
+// Clamping the COORDINATE to [0, N-1] is equivalent to clamping the two neighbour indices: outside that range both
+// neighbours clamp to the same voxel and lerp(a, a, t) == a exactly; at N-1 the weight of the upper neighbour is exactly
+// 0.  Coordinates are >= 0 after the clamp, so float->int truncation is floor() and v_fract_f32 is x - floor(x).
+// Because of the clamp every address is in bounds for ANY coordinate, so loads may be issued speculatively.
+template <int BPV, int LAYOUT> struct TriFetch {
+	// bricked: slice z quad, slice z+1 quad (u8: one dword each, u16: two dwords each);
+	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
+	uint32_t w0, w1, w2, w3;
+	float ax, ay, az;
+};
+
+template <int BPV, bool WIDE, int LAYOUT>
+__device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
+                                                           float xb, float yb, float zb) {
+	TriFetch<BPV, LAYOUT> f;
+	xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
+	yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
+	zb = __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
+	const uint32_t ix = (uint32_t) (int) xb, iy = (uint32_t) (int) yb, iz = (uint32_t) (int) zb;
+	f.ax = __builtin_amdgcn_fractf(xb); f.ay = __builtin_amdgcn_fractf(yb); f.az = __builtin_amdgcn_fractf(zb);
+	f.w0 = f.w1 = f.w2 = f.w3 = 0;
+	if (LAYOUT == kLayoutBricked) {
+		constexpr uint32_t kElem = 4 * BPV;
+		const uint8_t *q0, *q1;
+		if (WIDE) {
+			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
+			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
+			const uint32_t lxy = (dilate3(ix & 7u) << 1) | (dilate3(iy & 7u) << 2);
+			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz & 7u))) * kElem;
+			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz1 & 7u))) * kElem;
+		} else {
+			// per-axis element-offset tables in LDS (filled once per workgroup): brick base + Morton-dilated in-brick offset,
+			// split by axis; the z table holds {offset(z), offset(min(z+1, Z-1))} pairs so one ds_read_b64 serves both slices
+			const uint2 zz = *(const uint2 *) (lut + 2 * iz);
+			const uint32_t exy = lut[2 * a.dim_z + ix] + lut[2 * a.dim_z + a.dim_x + iy];
+			q0 = (const uint8_t *) vol + (uint64_t) (exy + zz.x) * kElem;
+			q1 = (const uint8_t *) vol + (uint64_t) (exy + zz.y) * kElem;
+		}
+		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
+			f.w0 = *(const uint32_t *) q0;
+			f.w1 = *(const uint32_t *) q1;
+		} else {                                         // 2 x global_load_dwordx2, 8-byte aligned
+			const uint2 lo = *(const uint2 *) q0, hi = *(const uint2 *) q1;
+			f.w0 = lo.x; f.w1 = lo.y; f.w2 = hi.x; f.w3 = hi.y;
+		}
 	} else {
-		uint32_t w;
-		__builtin_memcpy(&w, (const uint8_t *) vol + elem * 2, 4);
-		v0 = (float) (w & 0xffffu); v1 = (float) (w >> 16);
+		// LINEAR layout: one load per x-pair at VOXEL alignment (slow when the address is odd, see vr_device.h)
+		const uint8_t *p00, *p10, *p01, *p11;
+		if (WIDE) {
+			const uint64_t e = (((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix) * BPV;
+			p00 = (const uint8_t *) vol + e;
+			p10 = p00 + a.stride_y * BPV; p01 = p00 + a.stride_z * BPV; p11 = p01 + a.stride_y * BPV;
+		} else {
+			const uint32_t e = ((iz * a.dim_y + iy) * a.dim_x + ix) * (uint32_t) BPV;
+			const uint32_t sy = (uint32_t) a.stride_y * BPV, sz = (uint32_t) a.stride_z * BPV;
+			p00 = (const uint8_t *) vol + e;
+			p10 = (const uint8_t *) vol + (e + sy); p01 = (const uint8_t *) vol + (e + sz); p11 = (const uint8_t *) vol + (e + sz + sy);
+		}
+		if (BPV == 1) {
+			uint16_t h0, h1, h2, h3;
+			__builtin_memcpy(&h0, p00, 2); __builtin_memcpy(&h1, p10, 2); __builtin_memcpy(&h2, p01, 2); __builtin_memcpy(&h3, p11, 2);
+			f.w0 = h0; f.w1 = h1; f.w2 = h2; f.w3 = h3;
+		} else {
+			__builtin_memcpy(&f.w0, p00, 4); __builtin_memcpy(&f.w1, p10, 4); __builtin_memcpy(&f.w2, p01, 4); __builtin_memcpy(&f.w3, p11, 4);
+		}
 	}
+	return f;
 }
 
-// Manual trilinear fetch = tex3D with normalised coordinates, linear filter, clamp addressing
-// (GPURenderer4.cu:76,136-141).  xb = fma(pos, N/2, N/2 - 0.5) clamped to [0, N-1] is equivalent to clamping the two
-// neighbour indices: below 0 and above N-1 both neighbours clamp to the same voxel, and lerp(a, a, t) == a exactly.
-template <int BPV, bool WIDE>
-__device__ __forceinline__ float sample_trilinear(const void *vol, const RayKernelArgs &a, f3 pos) {
-	float xb = clampf(VR_FMA(pos.x, a.half_x, a.off_x), 0.0f, a.max_x);
-	float yb = clampf(VR_FMA(pos.y, a.half_y, a.off_y), 0.0f, a.max_y);
-	float zb = clampf(VR_FMA(pos.z, a.half_z, a.off_z), 0.0f, a.max_z);
-	float fx = __builtin_floorf(xb), fy = __builtin_floorf(yb), fz = __builtin_floorf(zb);
-	float ax = xb - fx, ay = yb - fy, az = zb - fz;
-	uint32_t ix = (uint32_t) (int) fx, iy = (uint32_t) (int) fy, iz = (uint32_t) (int) fz;
+// returns the interpolated RAW voxel value
+template <int BPV, int LAYOUT>
+__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f) {
 	float v000, v100, v010, v110, v001, v101, v011, v111;
-	if (WIDE) {
-		uint64_t e = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
-		load_pair<BPV>(vol, e, v000, v100);
-		load_pair<BPV>(vol, e + a.stride_y, v010, v110);
-		load_pair<BPV>(vol, e + a.stride_z, v001, v101);
-		load_pair<BPV>(vol, e + a.stride_z + a.stride_y, v011, v111);
+	if (LAYOUT == kLayoutBricked) {
+		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
+			v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v010 = (float) ((f.w0 >> 16) & 0xffu); v110 = (float) (f.w0 >> 24);
+			v001 = (float) (f.w1 & 0xffu); v101 = (float) ((f.w1 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
+		} else {
+			v000 = (float) (f.w0 & 0xffffu); v100 = (float) (f.w0 >> 16); v010 = (float) (f.w1 & 0xffffu); v110 = (float) (f.w1 >> 16);
+			v001 = (float) (f.w2 & 0xffffu); v101 = (float) (f.w2 >> 16); v011 = (float) (f.w3 & 0xffffu); v111 = (float) (f.w3 >> 16);
+		}
 	} else {
-		uint32_t e = (iz * a.dim_y + iy) * a.dim_x + ix;
-		uint32_t sy = (uint32_t) a.stride_y, sz = (uint32_t) a.stride_z;
-		load_pair<BPV>(vol, e, v000, v100);
-		load_pair<BPV>(vol, e + sy, v010, v110);
-		load_pair<BPV>(vol, e + sz, v001, v101);
-		load_pair<BPV>(vol, e + sz + sy, v011, v111);
+		if (BPV == 1) {
+			v000 = (float) (f.w0 & 0xffu); v100 = (float) (f.w0 >> 8); v010 = (float) (f.w1 & 0xffu); v110 = (float) (f.w1 >> 8);
+			v001 = (float) (f.w2 & 0xffu); v101 = (float) (f.w2 >> 8); v011 = (float) (f.w3 & 0xffu); v111 = (float) (f.w3 >> 8);
+		} else {
+			v000 = (float) (f.w0 & 0xffffu); v100 = (float) (f.w0 >> 16); v010 = (float) (f.w1 & 0xffffu); v110 = (float) (f.w1 >> 16);
+			v001 = (float) (f.w2 & 0xffffu); v101 = (float) (f.w2 >> 16); v011 = (float) (f.w3 & 0xffffu); v111 = (float) (f.w3 >> 16);
+		}
 	}
-	float c00 = lerp(v000, v100, ax), c10 = lerp(v010, v110, ax);
-	float c01 = lerp(v001, v101, ax), c11 = lerp(v011, v111, ax);
-	float c0 = lerp(c00, c10, ay), c1 = lerp(c01, c11, ay);
-	float c = lerp(c0, c1, az);
-	return c * (BPV == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
+	const float c00 = lerp(v000, v100, f.ax), c10 = lerp(v010, v110, f.ax);
+	const float c01 = lerp(v001, v101, f.ax), c11 = lerp(v011, v111, f.ax);
+	const float c0 = lerp(c00, c10, f.ay), c1 = lerp(c01, c11, f.ay);
+	return lerp(c0, c1, f.az);
+}
+
+// 1/sqrt(x) of the light vector in TRILINEAR mode: integer seed + three Newton steps in plain IEEE fp32 operations,
+// identical on CPU and GPU (oracle/vr_oracle.c rsqrt_nr); relative error < 2e-7.
+__device__ __forceinline__ float rsqrt_nr(float x) {
+	float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
+	const float h = 0.5f * x;
+	y = y * VR_FMA(-(h * y), y, 1.5f);
+	y = y * VR_FMA(-(h * y), y, 1.5f);
+	y = y * VR_FMA(-(h * y), y, 1.5f);
+	return y;
 }
 
 // ---- per-ray helpers (reference order of operations) ------------------------------------------------------------
@@ -180,15 +242,28 @@ __device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
 
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
-template <int SAMPLING, int BPV, bool WIDE>
+template <int SAMPLING, int BPV, bool WIDE, int LAYOUT>
 __global__ __launch_bounds__(256)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
 	__shared__ LdsTables lds;
+	extern __shared__ __attribute__((aligned(16))) uint32_t lut[];   // bricked TRILINEAR: per-axis byte-offset tables
 
-	// -- stage TF (+ deltas) and the ESL bit-volume in LDS
+	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
 		const uint32_t t = threadIdx.x;
+		if (SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && !WIDE) {
+			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
+			const uint32_t row = a.nbx * kBrickPitch, slab = a.nby * row;
+			// element indices; bytes = element * 4 * BPV (may exceed 4 GiB, the index does not)
+			for (uint32_t i = t; i < nz; i += 256) {
+				const uint32_t j = i + 1 < nz ? i + 1 : i;
+				lut[2 * i]     = (i >> 3) * slab + dilate3(i & 7u);
+				lut[2 * i + 1] = (j >> 3) * slab + dilate3(j & 7u);
+			}
+			for (uint32_t i = t; i < nx; i += 256) lut[2 * nz + i] = (i >> 3) * kBrickPitch + (dilate3(i & 7u) << 1);
+			for (uint32_t i = t; i < ny; i += 256) lut[2 * nz + nx + i] = (i >> 3) * row + (dilate3(i & 7u) << 2);
+		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
 			uint32_t i0 = t < VR_TF_SIZE ? t : VR_TF_SIZE - 1;
@@ -212,10 +287,13 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t tile = xcd * q + (xcd < r ? xcd : r) + slot;   // bijective for every ntiles
 	const uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
 
-	// -- one wavefront = one 8x8 pixel tile; 4 waves = 16x16
+	// -- one wavefront = one 8x8 pixel tile; 4 waves = 16x16.  Inside the wave each group of 16 consecutive lanes is a
+	//    4x4-pixel block (not two 8-pixel rows): the vector L1 coalesces per 16-lane group, and a compact block keeps the
+	//    group's samples inside the fewest 32-byte sectors whatever the view direction.
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	const uint32_t lx = tile_x * 16u + (wave & 1u) * 8u + (lane & 7u);
-	const uint32_t ly = tile_y * 16u + (wave >> 1) * 8u + (lane >> 3);
+	const uint32_t qd = lane >> 4;
+	const uint32_t lx = tile_x * 16u + (wave & 1u) * 8u + (qd & 1u) * 4u + (lane & 3u);
+	const uint32_t ly = tile_y * 16u + (wave >> 1) * 8u + (qd >> 1) * 4u + ((lane >> 2) & 3u);
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
@@ -243,15 +321,19 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	}
 	float kx = 0, ky = 0;
 	alive = alive && intersect(origin, dir, kx, ky);
-	const bool hit = alive;
 	const float step = a.p.ray_step;
+	// Termination guard, once per ray instead of a counter per sample: k advances by `step` every iteration as long as
+	// ky + step != ky (fp32 spacing grows with magnitude, so that holds for every k <= ky), and the march is cut after
+	// kMaxRaySteps steps.  Neither condition can trigger for a view the reference can produce (k spans <= 2*sqrt(3)).
+	alive = alive && (ky + step > ky);
+	ky = flmin(ky, kx + step * (float) kMaxRaySteps);
+	const bool hit = alive;
 	f3 pt = march_point<SAMPLING>(origin, dir, kx);
 
 	// -- empty space leaping loop (CPURenderer.cpp:18-25)
 	if (a.p.esl) {
 		bool probing = alive;
-		uint32_t guard = kMaxRaySteps;
-		while (__ballot(probing) != 0ull) {
+		while (__builtin_amdgcn_ballot_w64(probing) != 0ull) {
 			if (probing) {
 				if (kx <= ky && block_empty(lds, a, pt)) {
 					kx += leap_empty_space(a, pt, dir);
@@ -260,7 +342,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				} else {
 					probing = false;
 				}
-				if (--guard == 0) probing = false;
 			}
 		}
 	}
@@ -273,13 +354,11 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const float kd = a.p.light_kd;
 	const bool lit = kd > 0.01f;
 	const float threshold = a.p.ray_threshold;
-	uint32_t guard = kMaxRaySteps;
-	while (__ballot(alive) != 0ull) {               // wave-uniform exit: every lane terminated (ERT) or left the cube
-		if (alive) {
-			f4 cur;
-			if (SAMPLING == VR_SAMPLE_NEAREST) {
+	if (SAMPLING == VR_SAMPLE_NEAREST) {
+		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {           // wave-uniform exit: every lane terminated (ERT) or left the cube
+			if (alive) {
 				const uint32_t s = sample_nearest<BPV, WIDE>(vol, a, pt);
-				cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];          // CPURenderer.cpp:31
+				f4 cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];         // CPURenderer.cpp:31
 				if (cur.w > 0.05f && lit) {                                       // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
 					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
@@ -293,37 +372,55 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				const float t = 1 - acc.w;                                        // CPURenderer.cpp:34
 				acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
 				acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
-			} else {
-				const float s = sample_trilinear<BPV, WIDE>(vol, a, pt);          // GPURenderer4.cu:76
-				{                                                                  // GPURenderer4.cu:77 filtered TF
-					float xb = clampf(VR_FMA(s, (float) VR_TF_SIZE, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-					float fl = __builtin_floorf(xb);
-					float w = xb - fl;
-					uint32_t i = (uint32_t) (int) fl;
-					f4 c0 = lds.tf[i], dc = lds.dtf[i];
-					cur.x = VR_FMA(w, dc.x, c0.x); cur.y = VR_FMA(w, dc.y, c0.y);
-					cur.z = VR_FMA(w, dc.z, c0.z); cur.w = VR_FMA(w, dc.w, c0.w);
+				if (acc.w > threshold) {            // early ray termination (CPURenderer.cpp:35-36)
+					alive = false;
+				} else {
+					kx += step;
+					pt = march_point<SAMPLING>(origin, dir, kx);
+					alive = kx <= ky;
 				}
-				if (cur.w > 0.05f && lit) {                                       // GPURenderer4.cu:41-51 shade_texture
-					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
-					float inv = 1.0f / __builtin_sqrtf(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
-					f3 ps = mk3(VR_FMA(l.x, 0.01f, pt.x), VR_FMA(l.y, 0.01f, pt.y), VR_FMA(l.z, 0.01f, pt.z));
-					float sl = sample_trilinear<BPV, WIDE>(vol, a, ps);
-					float diffuse = (sl - s) * kd;
-					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
-				}
-				const float t = 1 - acc.w;
-				acc.x = VR_FMA(cur.x, t, acc.x); acc.y = VR_FMA(cur.y, t, acc.y);
-				acc.z = VR_FMA(cur.z, t, acc.z); acc.w = VR_FMA(cur.w, t, acc.w);
 			}
-			if (acc.w > threshold) {                // early ray termination (CPURenderer.cpp:35-36)
-				alive = false;
-			} else {
-				kx += step;
-				pt = march_point<SAMPLING>(origin, dir, kx);
-				alive = (kx <= ky) && (--guard != 0);
+		}
+	} else {
+		// texel-space ray: coordinate = fma(k, A, B) (see oracle/vr_oracle.c axis_setup)
+		const f3 A = mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z);
+		const f3 B = mk3(VR_FMA(origin.x, a.half_x, a.off_x), VR_FMA(origin.y, a.half_y, a.off_y), VR_FMA(origin.z, a.half_z, a.off_z));
+		// Lanes that are finished keep executing the (clamped, always in-bounds) fetch with a zero weight instead of being
+		// masked off: acc = fma(cur, 0, acc) leaves them bit-for-bit unchanged, and the loop body needs no per-lane
+		// control flow except the shading block.  The wave leaves when no lane is alive.
+		// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited,
+		// so one memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).
+		TriFetch<BPV, LAYOUT> cur = tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(kx, A.x, B.x), VR_FMA(kx, A.y, B.y), VR_FMA(kx, A.z, B.z));
+		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+			const float kn = kx + step;
+			const TriFetch<BPV, LAYOUT> nxt = tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(kn, A.x, B.x), VR_FMA(kn, A.y, B.y), VR_FMA(kn, A.z, B.z));
+			__builtin_amdgcn_sched_barrier(0);
+			const float raw = tri_resolve<BPV, LAYOUT>(cur);                                       // GPURenderer4.cu:76
+			f4 cur_c;
+			{                                                                                      // GPURenderer4.cu:77 filtered TF
+				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+				const uint32_t i = (uint32_t) (int) tb;
+				const float w = __builtin_amdgcn_fractf(tb);
+				const f4 c0 = lds.tf[i], dc = lds.dtf[i];
+				cur_c.x = VR_FMA(w, dc.x, c0.x); cur_c.y = VR_FMA(w, dc.y, c0.y);
+				cur_c.z = VR_FMA(w, dc.z, c0.z); cur_c.w = VR_FMA(w, dc.w, c0.w);
 			}
+			if (alive && cur_c.w > 0.05f && lit) {                                                 // GPURenderer4.cu:41-51 shade_texture
+				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
+				const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
+				const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
+				const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
+				const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
+				                                                                           VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
+				const float diffuse = (raw_l - raw) * a.kd_scaled;
+				cur_c.x += diffuse; cur_c.y += diffuse; cur_c.z += diffuse;
+			}
+			const float t = alive ? 1 - acc.w : 0.0f;
+			acc.x = VR_FMA(cur_c.x, t, acc.x); acc.y = VR_FMA(cur_c.y, t, acc.y);
+			acc.z = VR_FMA(cur_c.z, t, acc.z); acc.w = VR_FMA(cur_c.w, t, acc.w);
+			alive = alive && !(acc.w > threshold) && (kn <= ky);       // ERT (CPURenderer.cpp:35-36), then the loop condition
+			kx = kn;
+			cur = nxt;
 		}
 	}
 
@@ -336,32 +433,81 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	*out_px = rgba;
 }
 
-template <int SAMPLING, int BPV, bool WIDE>
+template <int SAMPLING, int BPV, bool WIDE, int LAYOUT>
 static hipError_t launch_variant(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
                                  void *out, hipStream_t stream) {
 	const uint32_t ntiles = a.tiles_x * a.tiles_y;
-	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, WIDE>), dim3(ntiles), dim3(256), 0, stream,
+	const size_t lut_bytes = (SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && !WIDE)
+	                             ? sizeof(uint32_t) * ((size_t) a.dim_x + a.dim_y + 2 * (size_t) a.dim_z) : 0;
+	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, WIDE, LAYOUT>), dim3(ntiles), dim3(256), lut_bytes, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
 }
 
+template <int BPV, bool WIDE>
+static hipError_t launch_mode(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
+                              void *out, hipStream_t stream) {
+	if (a.p.sampling == VR_SAMPLE_NEAREST)
+		return launch_variant<VR_SAMPLE_NEAREST, BPV, WIDE, kLayoutLinear>(a, volume, tf, esl, out, stream);
+	if (a.layout == kLayoutBricked)
+		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, WIDE, kLayoutBricked>(a, volume, tf, esl, out, stream);
+	return launch_variant<VR_SAMPLE_TRILINEAR, BPV, WIDE, kLayoutLinear>(a, volume, tf, esl, out, stream);
+}
+
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bpv, const float *tf,
                            const uint32_t *esl, void *out, hipStream_t stream) {
-	// 32-bit element offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size);
+	// 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size);
 	// larger ones (BASELINE config 5: 2048^3) take the 64-bit path.
-	const uint64_t elems = (uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y);
-	const bool wide = elems * bpv >= (1ull << 32);
-	const bool tri = a.p.sampling == VR_SAMPLE_TRILINEAR;
-	if (bpv == 1) {
-		if (tri) return wide ? launch_variant<VR_SAMPLE_TRILINEAR, 1, true>(a, volume, tf, esl, out, stream)
-		                     : launch_variant<VR_SAMPLE_TRILINEAR, 1, false>(a, volume, tf, esl, out, stream);
-		return wide ? launch_variant<VR_SAMPLE_NEAREST, 1, true>(a, volume, tf, esl, out, stream)
-		            : launch_variant<VR_SAMPLE_NEAREST, 1, false>(a, volume, tf, esl, out, stream);
+	const bool bricked = a.p.sampling == VR_SAMPLE_TRILINEAR && a.layout == kLayoutBricked;
+	bool wide;
+	if (bricked)   // 32-bit ELEMENT indices + 4*(dx+dy+dz) bytes of address tables in LDS
+		wide = bricked_elems(a.dim_x, a.dim_y, a.dim_z) >= (1ull << 32) || (uint64_t) a.dim_x + a.dim_y + 2ull * a.dim_z > 16384;
+	else           // 32-bit BYTE offsets
+		wide = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * bpv >= (1ull << 32);
+	if (bpv == 1) return wide ? launch_mode<1, true>(a, volume, tf, esl, out, stream) : launch_mode<1, false>(a, volume, tf, esl, out, stream);
+	return wide ? launch_mode<2, true>(a, volume, tf, esl, out, stream) : launch_mode<2, false>(a, volume, tf, esl, out, stream);
+}
+
+// ---- linear -> bricked copy ------------------------------------------------------------------------------------------
+
+template <int BPV>
+__global__ __launch_bounds__(256)
+void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                     uint32_t nbx, uint32_t nby, uint32_t nbz) {
+	typedef typename VoxelT<BPV>::type V;
+	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+		const uint64_t brick = o / kBrickPitch;
+		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
+		// undo the Morton order: bits 0,3,6 -> z, 1,4,7 -> x, 2,5,8 -> y
+		const uint32_t lz = (local & 1u) | ((local >> 2) & 2u) | ((local >> 4) & 4u);
+		const uint32_t lx = ((local >> 1) & 1u) | ((local >> 3) & 2u) | ((local >> 5) & 4u);
+		const uint32_t ly = ((local >> 2) & 1u) | ((local >> 4) & 2u) | ((local >> 6) & 4u);
+		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
+		const uint32_t by = br / nbx, bx = br - by * nbx;
+		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
+		V q[4] = { 0, 0, 0, 0 };
+		if (x < dim_x && y < dim_y && z < dim_z) {
+			// indices clamped at the upper faces: the clamped neighbours only ever get weight 0
+			const uint32_t zc = z;
+			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1;
+			const V *slice = (const V *) lin + (uint64_t) zc * dim_y * dim_x;
+			q[0] = slice[(uint64_t) y * dim_x + x];  q[1] = slice[(uint64_t) y * dim_x + x1];
+			q[2] = slice[(uint64_t) y1 * dim_x + x]; q[3] = slice[(uint64_t) y1 * dim_x + x1];
+		}
+		V *dst = (V *) out + o * 4;
+		dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 	}
-	if (tri) return wide ? launch_variant<VR_SAMPLE_TRILINEAR, 2, true>(a, volume, tf, esl, out, stream)
-	                     : launch_variant<VR_SAMPLE_TRILINEAR, 2, false>(a, volume, tf, esl, out, stream);
-	return wide ? launch_variant<VR_SAMPLE_NEAREST, 2, true>(a, volume, tf, esl, out, stream)
-	            : launch_variant<VR_SAMPLE_NEAREST, 2, false>(a, volume, tf, esl, out, stream);
+}
+
+hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                           hipStream_t stream) {
+	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge,
+	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
+	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	return hipGetLastError();
 }
 
 // ---- feeders: per-ESL-block min/max (RaycasterBase.cpp:101-117) as an HBM-streaming reduction --------------------------

@@ -66,6 +66,10 @@ class HipRenderer:
                     "set_volume_device")
         self.dims, self.bytes_per_voxel = tuple(dims), bytes_per_voxel
 
+    def set_layout(self, layout):
+        """LAYOUT_LINEAR | LAYOUT_BRICKED for the TRILINEAR copy of the volume (images are identical, speed is not)."""
+        self._check(self._L.vr_hip_set_layout(self._ctx, int(layout)), "set_layout")
+
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
         k = {"shell": 0, "noise": 1}[kind]
