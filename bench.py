@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = 16, or the whole frame at N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-band-rows", type=int, default=48, help="rows per view of the CPU-baseline sample")
+    ap.add_argument("--cpu-band-rows", type=int, default=96, help="rows per view of the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -59,12 +59,12 @@ def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
     vox = renderer.download_volume()
     if os.path.exists(ref_so):
         L = C.CDLL(ref_so)
-        L.volr_ref_init()
         devnull = os.open(os.devnull, os.O_WRONLY)      # the reference's Logger prints to stdout: keep our JSON line alone
         saved = os.dup(1)
         sys.stdout.flush()
         os.dup2(devnull, 1)
         try:
+            L.volr_ref_init()
             assert L.volr_ref_set_volume(vox.ctypes.data_as(C.POINTER(C.c_ubyte)), n, n, n) == 0
             L.volr_ref_set_params(C.c_float(scene.params.ray_step), C.c_float(scene.params.ray_threshold),
                                   C.c_float(scene.params.light_kd), int(scene.params.esl))
@@ -113,6 +113,19 @@ def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
             "sample": f"{len(views)} bands x {band_rows} rows (one per benchmark view) of the {width}x{height} frame = "
                       f"{rays} rays, {secs:.1f} s; NEAREST sampling (CPURenderer.cpp semantics), same volume/TF/mode",
             "ms_per_frame_extrapolated": round(secs / rays * width * height * 1e3, 1)}
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the PMC pass of the SAME command (profiles/r01_traffic.json, written by
+    scripts/profile_bench.sh from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).
+    None when no matching profile has been recorded — PMC counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec.get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -195,7 +208,8 @@ def main():
                        "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": 1, "ray_step": float(scene.params.ray_step),
                        "partition": f"{world} rank(s) x interleaved {band_rows}-row bands, RCCL gather to rank 0" if world > 1 else "single GPU, whole frame"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "vr::raymarch_kernel",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": recorded_traffic(f"{a.mode}_{a.sampling}_{n}_{W}_n{world}"), "kernel": "vr::raymarch_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "full march is gather/VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling')"},
             "minmax_feeder": {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),

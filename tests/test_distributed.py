@@ -1,0 +1,75 @@
+"""The multi-GPU path on CPU: world_size-2/3 `gloo` process groups run the SAME partition + gather code bench.py uses
+(volume-rendering_amd/distributed.py); each rank renders its bands with the CPU oracle standing in for the GPU kernel
+(test infrastructure only) and rank 0's assembled frame must equal the single-rank frame byte for byte."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, band_rows, label, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import Golden, Oracle
+        dmod = importlib.import_module("volume-rendering_amd.distributed")
+        golden, oracle = Golden(), Oracle()
+        case = [c for c in golden.cases(True) if c["label"] == label][0]
+        st = golden.volume_state(case["volume"])
+        p = golden.params(case, sampling=1)
+        split = dmod.FrameSplit(p.view.width, p.view.height, world, rank, band_rows)
+        local = torch.from_numpy(oracle.render(split.apply(p), golden.voxels(case["volume"]), st["tf"], st["esl"], threads=2))
+        assert tuple(local.shape) == (split.local_rows, p.view.width, 4)
+        frame = split.gather(local)
+        if rank == 0:
+            np.save(out_path, frame.numpy())
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,band_rows,label", [(2, 16, "window_199x178_view1"), (2, None, "bench64_view5_default"),
+                                                   (3, 8, "window_61x131_view6")])
+def test_gloo_frame_split_equals_single_rank(tmp_path, oracle, golden, world, band_rows, label):
+    out_path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), band_rows, label, out_path), nprocs=world, join=True)
+    case = [c for c in golden.cases(True) if c["label"] == label][0]
+    st = golden.volume_state(case["volume"])
+    whole = oracle.render(golden.params(case, sampling=1), golden.voxels(case["volume"]), st["tf"], st["esl"])
+    assert np.array_equal(np.load(out_path), whole)
+
+
+def test_assemble_is_the_inverse_of_the_band_map():
+    dmod = importlib.import_module("volume-rendering_amd.distributed")
+    W, H = 5, 37
+    frame = torch.arange(H, dtype=torch.uint8).view(H, 1, 1).expand(H, W, 4).contiguous()
+    for world, band in ((1, None), (2, 16), (3, 4), (4, 5), (8, 16), (2, 19)):
+        parts = []
+        for rank in range(world):
+            s = dmod.FrameSplit(W, H, world, rank, band)
+            local = torch.zeros((s.local_rows, W, 4), dtype=torch.uint8)
+            for ly in range(s.local_rows):
+                gy = ((ly // s.band_rows) * world + rank) * s.band_rows + ly % s.band_rows
+                if gy < H:
+                    local[ly] = frame[gy]
+            parts.append(local)
+        assert torch.equal(s.assemble(torch.stack(parts)), frame), (world, band)
