@@ -18,7 +18,7 @@ constexpr uint32_t kMaxRaySteps = 1u << 22;
 struct RayKernelArgs {
 	vr_params p;
 	uint32_t dim_x, dim_y, dim_z;      // Model::dims (ModelBase.h:13), widened
-	uint32_t tiles_x, tiles_y;         // 16x16-pixel workgroup tiles over the out_width x out_rows output
+	uint32_t tiles_x, tiles_y;         // 32x16-pixel workgroup tiles over the out_width x out_rows output
 	uint64_t stride_y, stride_z;       // voxel strides (elements): dim_x, dim_x*dim_y
 	float    half_x, half_y, half_z;   // 0.5f * dim  (TRILINEAR coordinate: xb = fma(pos, half, half - 0.5))
 	float    off_x,  off_y,  off_z;    // 0.5f * dim - 0.5f

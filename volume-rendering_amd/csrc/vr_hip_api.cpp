@@ -107,7 +107,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	memset(&a, 0, sizeof a);
 	a.p = *p;
 	a.dim_x = c->dim[0]; a.dim_y = c->dim[1]; a.dim_z = c->dim[2];
-	a.tiles_x = (p->out_width + 15u) / 16u; a.tiles_y = (p->out_rows + 15u) / 16u;
+	a.tiles_x = (p->out_width + 31u) / 32u; a.tiles_y = (p->out_rows + 15u) / 16u;
 	a.stride_y = c->dim[0]; a.stride_z = (uint64_t) c->dim[0] * c->dim[1];
 	a.half_x = 0.5f * (float) c->dim[0]; a.half_y = 0.5f * (float) c->dim[1]; a.half_z = 0.5f * (float) c->dim[2];
 	a.off_x = a.half_x - 0.5f; a.off_y = a.half_y - 0.5f; a.off_z = a.half_z - 0.5f;

@@ -45,16 +45,27 @@ struct __attribute__((aligned(16))) LdsTables {
 	uint32_t esl[VR_ESL_VOLUME_SIZE];
 };
 
+// Brick address tables (bricked TRILINEAR, dims <= kLutMaxDim): fixed LDS positions so the per-sample lookups are one
+// shift + one ds_read with an immediate offset each.  z pairs first (8-byte aligned), then x, then y.
+constexpr uint32_t kLutMaxDim = 1024;
+constexpr uint32_t kLutX = 2 * kLutMaxDim, kLutY = 3 * kLutMaxDim, kLutWords = 4 * kLutMaxDim;
+
+// How voxel addresses are formed (template parameter ADDR):
+//   kAddr32  : 32-bit BYTE offsets from a scalar base (global_load ... v_off, s[base:base+1]); volume copy < 4 GiB
+//   kAddrElem: 32-bit ELEMENT indices, 64-bit address arithmetic (bricked layout up to 2^32 elements)
+//   kAddrWide: full 64-bit index arithmetic, no LDS address tables (anything larger, e.g. 2048^3)
+enum : int { kAddr32 = 0, kAddrElem = 1, kAddrWide = 2 };
+
 template <int BPV> struct VoxelT;
 template <> struct VoxelT<1> { typedef uint8_t type; };
 template <> struct VoxelT<2> { typedef uint16_t type; };
 
 // ---- volume fetch --------------------------------------------------------------------------------------------
 
-template <int BPV, bool WIDE>
+template <int BPV, int ADDR>
 __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, uint32_t ix, uint32_t iy, uint32_t iz) {
 	typedef typename VoxelT<BPV>::type V;
-	if (WIDE) {
+	if (ADDR == kAddrWide) {
 		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
 		return ((const V *) vol)[idx];
 	} else {
@@ -64,12 +75,12 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 }
 
 // ModelBase.h:17-23 Model::sample_data
-template <int BPV, bool WIDE>
+template <int BPV, int ADDR>
 __device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKernelArgs &a, f3 pos) {
 	uint32_t iz = map_float_int((pos.z + 1) * 0.5f, a.dim_z);
 	uint32_t iy = map_float_int((pos.y + 1) * 0.5f, a.dim_y);
 	uint32_t ix = map_float_int((pos.x + 1) * 0.5f, a.dim_x);
-	return fetch_voxel<BPV, WIDE>(vol, a, ix, iy, iz);
+	return fetch_voxel<BPV, ADDR>(vol, a, ix, iy, iz);
 }
 
 __device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
@@ -90,7 +101,7 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	float ax, ay, az;
 };
 
-template <int BPV, bool WIDE, int LAYOUT>
+template <int BPV, int ADDR, int LAYOUT>
 __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
                                                            float xb, float yb, float zb) {
 	TriFetch<BPV, LAYOUT> f;
@@ -103,19 +114,25 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 	if (LAYOUT == kLayoutBricked) {
 		constexpr uint32_t kElem = 4 * BPV;
 		const uint8_t *q0, *q1;
-		if (WIDE) {
+		if (ADDR == kAddrWide) {
 			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
 			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
 			const uint32_t lxy = (dilate3(ix & 7u) << 1) | (dilate3(iy & 7u) << 2);
 			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz & 7u))) * kElem;
 			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz1 & 7u))) * kElem;
 		} else {
-			// per-axis element-offset tables in LDS (filled once per workgroup): brick base + Morton-dilated in-brick offset,
-			// split by axis; the z table holds {offset(z), offset(min(z+1, Z-1))} pairs so one ds_read_b64 serves both slices
+			// per-axis offset tables in LDS at FIXED positions (filled once per workgroup): brick base + Morton-dilated
+			// in-brick offset, split by axis; the z table holds {offset(z), offset(min(z+1, Z-1))} pairs so one ds_read_b64
+			// serves both slices.  kAddr32: the tables hold byte offsets, kAddrElem: element indices.
 			const uint2 zz = *(const uint2 *) (lut + 2 * iz);
-			const uint32_t exy = lut[2 * a.dim_z + ix] + lut[2 * a.dim_z + a.dim_x + iy];
-			q0 = (const uint8_t *) vol + (uint64_t) (exy + zz.x) * kElem;
-			q1 = (const uint8_t *) vol + (uint64_t) (exy + zz.y) * kElem;
+			const uint32_t exy = lut[kLutX + ix] + lut[kLutY + iy];
+			if (ADDR == kAddr32) {
+				q0 = (const uint8_t *) vol + (exy + zz.x);
+				q1 = (const uint8_t *) vol + (exy + zz.y);
+			} else {
+				q0 = (const uint8_t *) vol + (uint64_t) (exy + zz.x) * kElem;
+				q1 = (const uint8_t *) vol + (uint64_t) (exy + zz.y) * kElem;
+			}
 		}
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
 			f.w0 = *(const uint32_t *) q0;
@@ -127,7 +144,7 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 	} else {
 		// LINEAR layout: one load per x-pair at VOXEL alignment (slow when the address is odd, see vr_device.h)
 		const uint8_t *p00, *p10, *p01, *p11;
-		if (WIDE) {
+		if (ADDR == kAddrWide) {
 			const uint64_t e = (((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix) * BPV;
 			p00 = (const uint8_t *) vol + e;
 			p10 = p00 + a.stride_y * BPV; p01 = p00 + a.stride_z * BPV; p11 = p01 + a.stride_y * BPV;
@@ -242,27 +259,31 @@ __device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
 
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
-template <int SAMPLING, int BPV, bool WIDE, int LAYOUT>
-__global__ __launch_bounds__(256)
+constexpr uint32_t kThreads = 512;      // 8 waves = 32x16 pixels: one copy of the LDS tables serves twice the rays, and
+                                        // 4 workgroups per CU reach the 32-wave limit inside the 160 KiB of LDS
+
+template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
+__global__ __launch_bounds__(kThreads)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
+	constexpr bool kUseLut = SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && ADDR != kAddrWide;
 	__shared__ LdsTables lds;
-	extern __shared__ __attribute__((aligned(16))) uint32_t lut[];   // bricked TRILINEAR: per-axis byte-offset tables
+	__shared__ __attribute__((aligned(16))) uint32_t lut[kUseLut ? kLutWords : 4];
 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
 		const uint32_t t = threadIdx.x;
-		if (SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && !WIDE) {
+		if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
+			const uint32_t scale = ADDR == kAddr32 ? 4u * BPV : 1u;        // byte offsets or element indices
 			const uint32_t row = a.nbx * kBrickPitch, slab = a.nby * row;
-			// element indices; bytes = element * 4 * BPV (may exceed 4 GiB, the index does not)
-			for (uint32_t i = t; i < nz; i += 256) {
+			for (uint32_t i = t; i < nz; i += kThreads) {
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
-				lut[2 * i]     = (i >> 3) * slab + dilate3(i & 7u);
-				lut[2 * i + 1] = (j >> 3) * slab + dilate3(j & 7u);
+				lut[2 * i]     = ((i >> 3) * slab + dilate3(i & 7u)) * scale;
+				lut[2 * i + 1] = ((j >> 3) * slab + dilate3(j & 7u)) * scale;
 			}
-			for (uint32_t i = t; i < nx; i += 256) lut[2 * nz + i] = (i >> 3) * kBrickPitch + (dilate3(i & 7u) << 1);
-			for (uint32_t i = t; i < ny; i += 256) lut[2 * nz + nx + i] = (i >> 3) * row + (dilate3(i & 7u) << 2);
+			for (uint32_t i = t; i < nx; i += kThreads) lut[kLutX + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << 1)) * scale;
+			for (uint32_t i = t; i < ny; i += kThreads) lut[kLutY + i] = ((i >> 3) * row + (dilate3(i & 7u) << 2)) * scale;
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -273,8 +294,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			f4 d; d.x = c1.x - c0.x; d.y = c1.y - c0.y; d.z = c1.z - c0.z; d.w = c1.w - c0.w;
 			lds.dtf[t] = d;
 		}
-		const uint4 *e4 = (const uint4 *) esl_g;
-		((uint4 *) lds.esl)[t] = e4[t];            // 256 threads x 16 B = 4 KiB
+		((uint2 *) lds.esl)[t] = ((const uint2 *) esl_g)[t];       // 512 threads x 8 B = 4 KiB
 	}
 	__syncthreads();
 
@@ -287,13 +307,13 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t tile = xcd * q + (xcd < r ? xcd : r) + slot;   // bijective for every ntiles
 	const uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
 
-	// -- one wavefront = one 8x8 pixel tile; 4 waves = 16x16.  Inside the wave each group of 16 consecutive lanes is a
+	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16.  Inside the wave each group of 16 consecutive lanes is a
 	//    4x4-pixel block (not two 8-pixel rows): the vector L1 coalesces per 16-lane group, and a compact block keeps the
 	//    group's samples inside the fewest 32-byte sectors whatever the view direction.
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t qd = lane >> 4;
-	const uint32_t lx = tile_x * 16u + (wave & 1u) * 8u + (qd & 1u) * 4u + (lane & 3u);
-	const uint32_t ly = tile_y * 16u + (wave >> 1) * 8u + (qd >> 1) * 4u + ((lane >> 2) & 3u);
+	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + (qd & 1u) * 4u + (lane & 3u);
+	const uint32_t ly = tile_y * 16u + (wave >> 2) * 8u + (qd >> 1) * 4u + ((lane >> 2) & 3u);
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
@@ -357,7 +377,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	if (SAMPLING == VR_SAMPLE_NEAREST) {
 		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {           // wave-uniform exit: every lane terminated (ERT) or left the cube
 			if (alive) {
-				const uint32_t s = sample_nearest<BPV, WIDE>(vol, a, pt);
+				const uint32_t s = sample_nearest<BPV, ADDR>(vol, a, pt);
 				f4 cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];         // CPURenderer.cpp:31
 				if (cur.w > 0.05f && lit) {                                       // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
@@ -365,7 +385,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
-					float sl = (float) sample_nearest<BPV, WIDE>(vol, a, ps) / raw;
+					float sl = (float) sample_nearest<BPV, ADDR>(vol, a, ps) / raw;
 					float diffuse = (sl - (float) s / raw) * kd;
 					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				}
@@ -388,39 +408,47 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// Lanes that are finished keep executing the (clamped, always in-bounds) fetch with a zero weight instead of being
 		// masked off: acc = fma(cur, 0, acc) leaves them bit-for-bit unchanged, and the loop body needs no per-lane
 		// control flow except the shading block.  The wave leaves when no lane is alive.
-		// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited,
-		// so one memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).
-		TriFetch<BPV, LAYOUT> cur = tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(kx, A.x, B.x), VR_FMA(kx, A.y, B.y), VR_FMA(kx, A.z, B.z));
-		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+		// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited, so one
+		// memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).  The
+		// body is written once (`step_sample`) and instantiated twice per iteration with the two fetch slots swapped: no
+		// register copies, one exit vote per two samples (a finished wave at worst composites one more weight-0 sample).
+		auto issue = [&](float k) {
+			return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z));
+		};
+		auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
 			const float kn = kx + step;
-			const TriFetch<BPV, LAYOUT> nxt = tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(kn, A.x, B.x), VR_FMA(kn, A.y, B.y), VR_FMA(kn, A.z, B.z));
+			nxt = issue(kn);
 			__builtin_amdgcn_sched_barrier(0);
 			const float raw = tri_resolve<BPV, LAYOUT>(cur);                                       // GPURenderer4.cu:76
-			f4 cur_c;
+			f4 c;
 			{                                                                                      // GPURenderer4.cu:77 filtered TF
 				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
 				const uint32_t i = (uint32_t) (int) tb;
 				const float w = __builtin_amdgcn_fractf(tb);
 				const f4 c0 = lds.tf[i], dc = lds.dtf[i];
-				cur_c.x = VR_FMA(w, dc.x, c0.x); cur_c.y = VR_FMA(w, dc.y, c0.y);
-				cur_c.z = VR_FMA(w, dc.z, c0.z); cur_c.w = VR_FMA(w, dc.w, c0.w);
+				c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
+				c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
 			}
-			if (alive && cur_c.w > 0.05f && lit) {                                                 // GPURenderer4.cu:41-51 shade_texture
+			if (alive && c.w > 0.05f && lit) {                                                     // GPURenderer4.cu:41-51 shade_texture
 				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
 				const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
 				const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
 				const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-				const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, WIDE, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
-				                                                                           VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
+				const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
+				                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
 				const float diffuse = (raw_l - raw) * a.kd_scaled;
-				cur_c.x += diffuse; cur_c.y += diffuse; cur_c.z += diffuse;
+				c.x += diffuse; c.y += diffuse; c.z += diffuse;
 			}
 			const float t = alive ? 1 - acc.w : 0.0f;
-			acc.x = VR_FMA(cur_c.x, t, acc.x); acc.y = VR_FMA(cur_c.y, t, acc.y);
-			acc.z = VR_FMA(cur_c.z, t, acc.z); acc.w = VR_FMA(cur_c.w, t, acc.w);
+			acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
+			acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
 			alive = alive && !(acc.w > threshold) && (kn <= ky);       // ERT (CPURenderer.cpp:35-36), then the loop condition
 			kx = kn;
-			cur = nxt;
+		};
+		TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
+		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+			step_sample(fa, fb);
+			step_sample(fb, fa);
 		}
 	}
 
@@ -433,39 +461,40 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	*out_px = rgba;
 }
 
-template <int SAMPLING, int BPV, bool WIDE, int LAYOUT>
+template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
 static hipError_t launch_variant(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
                                  void *out, hipStream_t stream) {
 	const uint32_t ntiles = a.tiles_x * a.tiles_y;
-	const size_t lut_bytes = (SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && !WIDE)
-	                             ? sizeof(uint32_t) * ((size_t) a.dim_x + a.dim_y + 2 * (size_t) a.dim_z) : 0;
-	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, WIDE, LAYOUT>), dim3(ntiles), dim3(256), lut_bytes, stream,
+	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(ntiles), dim3(kThreads), 0, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
 }
 
-template <int BPV, bool WIDE>
-static hipError_t launch_mode(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
-                              void *out, hipStream_t stream) {
-	if (a.p.sampling == VR_SAMPLE_NEAREST)
-		return launch_variant<VR_SAMPLE_NEAREST, BPV, WIDE, kLayoutLinear>(a, volume, tf, esl, out, stream);
-	if (a.layout == kLayoutBricked)
-		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, WIDE, kLayoutBricked>(a, volume, tf, esl, out, stream);
-	return launch_variant<VR_SAMPLE_TRILINEAR, BPV, WIDE, kLayoutLinear>(a, volume, tf, esl, out, stream);
+template <int BPV>
+static hipError_t launch_bpv(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
+                             void *out, hipStream_t stream) {
+	const uint64_t lin_bytes = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV;
+	if (a.p.sampling == VR_SAMPLE_NEAREST || a.layout == kLayoutLinear) {
+		// 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size)
+		const bool wide = lin_bytes >= (1ull << 32);
+		if (a.p.sampling == VR_SAMPLE_NEAREST)
+			return wide ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrWide, kLayoutLinear>(a, volume, tf, esl, out, stream)
+			            : launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutLinear>(a, volume, tf, esl, out, stream);
+		return wide ? launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutLinear>(a, volume, tf, esl, out, stream)
+		            : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutLinear>(a, volume, tf, esl, out, stream);
+	}
+	const uint64_t elems = bricked_elems(a.dim_x, a.dim_y, a.dim_z);
+	const bool lut_ok = a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
+	if (lut_ok && elems * 4 * BPV <= (1ull << 32))
+		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, volume, tf, esl, out, stream);
+	if (lut_ok && elems < (1ull << 32))
+		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrElem, kLayoutBricked>(a, volume, tf, esl, out, stream);
+	return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, volume, tf, esl, out, stream);   // e.g. 2048^3
 }
 
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bpv, const float *tf,
                            const uint32_t *esl, void *out, hipStream_t stream) {
-	// 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size);
-	// larger ones (BASELINE config 5: 2048^3) take the 64-bit path.
-	const bool bricked = a.p.sampling == VR_SAMPLE_TRILINEAR && a.layout == kLayoutBricked;
-	bool wide;
-	if (bricked)   // 32-bit ELEMENT indices + 4*(dx+dy+dz) bytes of address tables in LDS
-		wide = bricked_elems(a.dim_x, a.dim_y, a.dim_z) >= (1ull << 32) || (uint64_t) a.dim_x + a.dim_y + 2ull * a.dim_z > 16384;
-	else           // 32-bit BYTE offsets
-		wide = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * bpv >= (1ull << 32);
-	if (bpv == 1) return wide ? launch_mode<1, true>(a, volume, tf, esl, out, stream) : launch_mode<1, false>(a, volume, tf, esl, out, stream);
-	return wide ? launch_mode<2, true>(a, volume, tf, esl, out, stream) : launch_mode<2, false>(a, volume, tf, esl, out, stream);
+	return bpv == 1 ? launch_bpv<1>(a, volume, tf, esl, out, stream) : launch_bpv<2>(a, volume, tf, esl, out, stream);
 }
 
 // ---- linear -> bricked copy ------------------------------------------------------------------------------------------
