@@ -129,6 +129,12 @@ def recorded_traffic(key):
 
 
 def main():
+    # Rank 0 must print exactly ONE line on stdout.  Native libraries in this process write there too (RCCL prints a version
+    # banner on init, the reference's Logger prints on init), so file descriptor 1 is pointed at stderr for the whole run
+    # and the JSON line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,8 +145,11 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)      # "nccl" IS RCCL on ROCm
+    distributed = world > 1 or "RANK" in os.environ            # under torch.distributed.run even N=1 goes through RCCL
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)      # "nccl" IS RCCL on ROCm
 
     vr = importlib.import_module("volume-rendering_amd")
     dmod = importlib.import_module("volume-rendering_amd.distributed")
@@ -160,18 +169,30 @@ def main():
 
     band_rows = a.band_rows or dmod.default_band_rows(H, world)
     split = dmod.FrameSplit(W, H, world, rank, band_rows)
-    local = split.local_buffer(device)
-    staging = split.staging_buffer(device) if (rank == 0 and world > 1) else None
+    # two frames in flight: frame i+1 is rendered while the bands of frame i travel to rank 0 on RCCL's stream
+    local = [split.local_buffer(device) for _ in range(2)]
+    staging = [split.staging_buffer(device) if (rank == 0 and distributed) else None for _ in range(2)]
+    pending = [None, None]
     params = [split.apply(scene.frame_params(v, sampling)) for v in views]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):
-        r.render_volume_device(params[i % 8], local.data_ptr(), stream)
-        return split.gather(local, staging)
+        slot = i & 1
+        if pending[slot] is not None:
+            pending[slot][0].wait()                 # the buffer pair of frame i-2 is free again
+            pending[slot] = None
+        r.render_volume_device(params[i % 8], local[slot].data_ptr(), stream)
+        work, finish = split.gather_async(local[slot], staging[slot])
+        if work is not None:
+            pending[slot] = (work, finish)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        for slot in range(2):
+            if pending[slot] is not None:
+                pending[slot][0].wait()
+                pending[slot] = None
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -184,7 +205,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tm = r.timing()
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed, tm.kernel_ms_sum / max(1, tm.launches)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -206,7 +227,7 @@ def main():
                                    f"mode={a.mode} ({'ESL off, threshold 1.0' if a.mode == 'nooptims' else 'ESL on, threshold 0.95'}, "
                                    f"light_kd 0.6), sampling={a.sampling}",
                        "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": 1, "ray_step": float(scene.params.ray_step),
-                       "partition": f"{world} rank(s) x interleaved {band_rows}-row bands, RCCL gather to rank 0" if world > 1 else "single GPU, whole frame"},
+                       "partition": f"{world} rank(s) x interleaved {band_rows}-row bands, RCCL gather to rank 0, 2 frames in flight" if world > 1 else "single GPU, whole frame"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(f"{a.mode}_{a.sampling}_{n}_{W}_n{world}"), "kernel": "vr::raymarch_kernel",
@@ -227,12 +248,12 @@ def main():
                     scene.set_modes(esl=True, ray_threshold=0.95)
                 ps = [split.apply(scene.frame_params(v, samp)) for v in views]
                 for p in ps:
-                    r.render_volume_device(p, local.data_ptr(), stream)
+                    r.render_volume_device(p, local[0].data_ptr(), stream)
                 torch.cuda.synchronize()
                 r.timing_reset()
                 t1 = time.perf_counter()
                 for p in ps:
-                    r.render_volume_device(p, local.data_ptr(), stream)
+                    r.render_volume_device(p, local[0].data_ptr(), stream)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t1) / 8
                 extras[label] = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_per_s": round(W * H / dt / 1e6, 1)}
@@ -245,9 +266,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     r.close()
 

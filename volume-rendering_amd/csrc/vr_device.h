@@ -26,7 +26,8 @@ struct RayKernelArgs {
 	float    lh_x,   lh_y,   lh_z;     // 0.01f * half: texel-space length of the shading offset (GPURenderer4.cu:43-46)
 	float    tf_scale;                 // 128/255 (u8) or 128/65535 (u16): raw interpolated voxel -> TF texel coordinate + 0.5
 	float    kd_scaled;                // light_kd / 255 (u8) or / 65535 (u16)
-	uint32_t layout;                   // vr_layout of the TRILINEAR volume
+	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
+	uint32_t layout;                   // vr_layout in use for this launch
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
 
@@ -66,8 +67,8 @@ inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 	       ((dim_z + kBrickEdge - 1) / kBrickEdge) * kBrickPitch;
 }
 
-// `volume` is the linear array for NEAREST sampling and for TRILINEAR with kLayoutLinear, the bricked copy otherwise.
-hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bytes_per_voxel,
+// `linear` is the reference's array (always resident); `bricked` the quad-brick copy or NULL (VR_LAYOUT_LINEAR).
+hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bytes_per_voxel,
                            const float *tf_premult /* 128 x float4 */, const uint32_t *esl_bits /* 1024 */,
                            void *out_rgba, hipStream_t stream);
 

@@ -91,8 +91,8 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 		return fail(c, VR_ERR_INVALID, "ray_step must be finite and >= 1e-6");
 	if (!std::isfinite(p->ray_threshold) || !std::isfinite(p->light_kd))
 		return fail(c, VR_ERR_INVALID, "ray_threshold / light_kd must be finite");
-	if (p->esl && (p->esl_block_dims == 0 || !finite3(p->esl_block_size)))
-		return fail(c, VR_ERR_INVALID, "esl_block_dims must be > 0 and esl_block_size finite when esl is on");
+	if (p->esl && (p->esl_block_dims == 0 || p->esl_block_dims > 65535u || !finite3(p->esl_block_size)))   // unsigned short in the reference
+		return fail(c, VR_ERR_INVALID, "esl_block_dims must be in 1..65535 and esl_block_size finite when esl is on");
 	if (p->sampling != VR_SAMPLE_NEAREST && p->sampling != VR_SAMPLE_TRILINEAR)
 		return fail(c, VR_ERR_INVALID, "unknown sampling mode");
 	if (p->out_width == 0 || p->out_rows == 0 || p->out_width > 65535u || p->out_rows > 65535u)
@@ -118,13 +118,17 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
-	const void *volume = (p->sampling == VR_SAMPLE_TRILINEAR && c->vol_bricked) ? c->vol_bricked : c->vol;
+	{   // RaycasterBase.h:59-63: index / esl_block_dims, prepared as shift or multiply-high
+		const uint32_t bd = p->esl_block_dims ? p->esl_block_dims : 1u;
+		if ((bd & (bd - 1)) == 0) { a.esl_div_magic = 0; a.esl_div_shift = (uint32_t) __builtin_ctz(bd); }
+		else { a.esl_div_magic = (uint32_t) ((1ull << 32) / bd + 1); a.esl_div_shift = 0; }
+	}
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
 	VR_TRY(c, hipEventRecord(ev.start, stream));
-	VR_TRY(c, launch_raymarch(a, volume, c->bpv, c->tf, c->esl, dev_rgba, stream));
+	VR_TRY(c, launch_raymarch(a, c->vol, c->vol_bricked, c->bpv, c->tf, c->esl, dev_rgba, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
 	return VR_OK;

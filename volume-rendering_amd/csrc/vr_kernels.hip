@@ -62,9 +62,18 @@ template <> struct VoxelT<2> { typedef uint16_t type; };
 
 // ---- volume fetch --------------------------------------------------------------------------------------------
 
-template <int BPV, int ADDR>
-__device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, uint32_t ix, uint32_t iy, uint32_t iz) {
+// Single voxel (NEAREST).  LINEAR: the reference's array.  BRICKED: component 0 of the quad element (x,y,z) IS v(x,y,z), so
+// NEAREST reads the same Z-ordered bricks as TRILINEAR with one aligned element load and keeps their view-independent
+// cache-line footprint; the value — hence the image — is identical.
+template <int BPV, int ADDR, int LAYOUT>
+__device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
+                                                uint32_t ix, uint32_t iy, uint32_t iz) {
 	typedef typename VoxelT<BPV>::type V;
+	if (LAYOUT == kLayoutBricked) {
+		const uint32_t off = lut[2 * iz] + lut[kLutX + ix] + lut[kLutY + iy];      // byte offset (kAddr32 tables)
+		if (BPV == 1) return *(const uint32_t *) ((const uint8_t *) vol + off) & 0xffu;
+		return *(const uint32_t *) ((const uint8_t *) vol + off) & 0xffffu;
+	}
 	if (ADDR == kAddrWide) {
 		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
 		return ((const V *) vol)[idx];
@@ -75,12 +84,12 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 }
 
 // ModelBase.h:17-23 Model::sample_data
-template <int BPV, int ADDR>
-__device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKernelArgs &a, f3 pos) {
+template <int BPV, int ADDR, int LAYOUT>
+__device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 pos) {
 	uint32_t iz = map_float_int((pos.z + 1) * 0.5f, a.dim_z);
 	uint32_t iy = map_float_int((pos.y + 1) * 0.5f, a.dim_y);
 	uint32_t ix = map_float_int((pos.x + 1) * 0.5f, a.dim_x);
-	return fetch_voxel<BPV, ADDR>(vol, a, ix, iy, iz);
+	return fetch_voxel<BPV, ADDR, LAYOUT>(vol, a, lut, ix, iy, iz);
 }
 
 __device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
@@ -219,22 +228,32 @@ __device__ __forceinline__ bool intersect(f3 pt, f3 dir, float &kx, float &ky) {
 	return (kx < ky) && (ky > 0);
 }
 
+// n / esl_block_dims for n < 65536 without an integer divide: shift when the block edge is a power of two, otherwise the
+// high half of n * (floor(2^32 / d) + 1), which is exact for n * d < 2^32 (host: RayKernelArgs::esl_div_*).
+__device__ __forceinline__ uint32_t block_of(const RayKernelArgs &a, uint32_t n) {
+	return a.esl_div_magic ? __umulhi(n, a.esl_div_magic) : (n >> a.esl_div_shift);
+}
+
+struct BlockIdx { uint32_t x, y, z; };
+// block coordinates of a position: map_float_int((p + 1) / 2, dim) / esl_block_dims per axis (RaycasterBase.h:59-63,69-73)
+__device__ __forceinline__ BlockIdx block_index(const RayKernelArgs &a, f3 pos) {
+	BlockIdx b;
+	b.x = block_of(a, map_float_int((pos.x + 1) * 0.5f, a.dim_x));
+	b.y = block_of(a, map_float_int((pos.y + 1) * 0.5f, a.dim_y));
+	b.z = block_of(a, map_float_int((pos.z + 1) * 0.5f, a.dim_z));
+	return b;
+}
+
 // RaycasterBase.h:52-65 Raycaster::sample_data_esl — bit set = block is empty; table read from LDS
-__device__ __forceinline__ bool block_empty(const LdsTables &t, const RayKernelArgs &a, f3 pos) {
-	const uint32_t bd = a.p.esl_block_dims;
-	uint32_t index = ((map_float_int((pos.z + 1) * 0.5f, a.dim_z) / bd) * VR_ESL_VOLUME_DIMS +
-	                  (map_float_int((pos.y + 1) * 0.5f, a.dim_y) / bd)) & 0xffffu;
-	uint32_t word = t.esl[index & (VR_ESL_VOLUME_SIZE - 1)];
-	uint32_t bit = map_float_int((pos.x + 1) * 0.5f, a.dim_x) / bd;
-	return (word & (1u << (bit & 31u))) != 0;
+__device__ __forceinline__ bool block_empty(const LdsTables &t, BlockIdx b) {
+	const uint32_t index = (b.z * VR_ESL_VOLUME_DIMS + b.y) & 0xffffu;          // `unsigned short index` in the reference
+	const uint32_t word = t.esl[index & (VR_ESL_VOLUME_SIZE - 1)];
+	return (word & (1u << (b.x & 31u))) != 0;
 }
 
 // RaycasterBase.h:67-85 Raycaster::leap_empty_space
-__device__ __forceinline__ float leap_empty_space(const RayKernelArgs &a, f3 pt, f3 dir) {
-	const uint32_t bd = a.p.esl_block_dims;
-	uint32_t ix = map_float_int((pt.x + 1) * 0.5f, a.dim_x) / bd;
-	uint32_t iy = map_float_int((pt.y + 1) * 0.5f, a.dim_y) / bd;
-	uint32_t iz = map_float_int((pt.z + 1) * 0.5f, a.dim_z) / bd;
+__device__ __forceinline__ float leap_empty_space(const RayKernelArgs &a, BlockIdx b, f3 pt, f3 dir) {
+	uint32_t ix = b.x, iy = b.y, iz = b.z;
 	if (dir.x > 0) ix++;
 	if (dir.y > 0) iy++;
 	if (dir.z > 0) iz++;
@@ -266,7 +285,7 @@ template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
 __global__ __launch_bounds__(kThreads)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
-	constexpr bool kUseLut = SAMPLING == VR_SAMPLE_TRILINEAR && LAYOUT == kLayoutBricked && ADDR != kAddrWide;
+	constexpr bool kUseLut = LAYOUT == kLayoutBricked && ADDR != kAddrWide;
 	__shared__ LdsTables lds;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[kUseLut ? kLutWords : 4];
 
@@ -355,8 +374,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		bool probing = alive;
 		while (__builtin_amdgcn_ballot_w64(probing) != 0ull) {
 			if (probing) {
-				if (kx <= ky && block_empty(lds, a, pt)) {
-					kx += leap_empty_space(a, pt, dir);
+				const BlockIdx blk = block_index(a, pt);
+				if (kx <= ky && block_empty(lds, blk)) {
+					kx += leap_empty_space(a, blk, pt, dir);
 					kx += step;
 					pt = march_point<SAMPLING>(origin, dir, kx);
 				} else {
@@ -377,7 +397,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	if (SAMPLING == VR_SAMPLE_NEAREST) {
 		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {           // wave-uniform exit: every lane terminated (ERT) or left the cube
 			if (alive) {
-				const uint32_t s = sample_nearest<BPV, ADDR>(vol, a, pt);
+				const uint32_t s = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pt);
 				f4 cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];         // CPURenderer.cpp:31
 				if (cur.w > 0.05f && lit) {                                       // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
@@ -385,7 +405,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
-					float sl = (float) sample_nearest<BPV, ADDR>(vol, a, ps) / raw;
+					float sl = (float) sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps) / raw;
 					float diffuse = (sl - (float) s / raw) * kd;
 					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				}
@@ -471,30 +491,33 @@ static hipError_t launch_variant(const RayKernelArgs &a, const void *volume, con
 }
 
 template <int BPV>
-static hipError_t launch_bpv(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
-                             void *out, hipStream_t stream) {
-	const uint64_t lin_bytes = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV;
-	if (a.p.sampling == VR_SAMPLE_NEAREST || a.layout == kLayoutLinear) {
-		// 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12, unsigned int size)
-		const bool wide = lin_bytes >= (1ull << 32);
-		if (a.p.sampling == VR_SAMPLE_NEAREST)
-			return wide ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrWide, kLayoutLinear>(a, volume, tf, esl, out, stream)
-			            : launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutLinear>(a, volume, tf, esl, out, stream);
-		return wide ? launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutLinear>(a, volume, tf, esl, out, stream)
-		            : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutLinear>(a, volume, tf, esl, out, stream);
+static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
+                             const uint32_t *esl, void *out, hipStream_t stream) {
+	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
+	if (bricked != nullptr) {
+		const uint64_t elems = bricked_elems(a.dim_x, a.dim_y, a.dim_z);
+		const bool lut_ok = a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
+		if (lut_ok && elems * 4 * BPV <= (1ull << 32))
+			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream)
+			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+		if (!nearest) {
+			if (lut_ok && elems < (1ull << 32))
+				return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrElem, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);   // e.g. 2048^3
+		}
 	}
-	const uint64_t elems = bricked_elems(a.dim_x, a.dim_y, a.dim_z);
-	const bool lut_ok = a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
-	if (lut_ok && elems * 4 * BPV <= (1ull << 32))
-		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, volume, tf, esl, out, stream);
-	if (lut_ok && elems < (1ull << 32))
-		return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrElem, kLayoutBricked>(a, volume, tf, esl, out, stream);
-	return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, volume, tf, esl, out, stream);   // e.g. 2048^3
+	// the reference's linear array; 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12)
+	const bool wide = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);
+	if (nearest)
+		return wide ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
+		            : launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
+	return wide ? launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
+	            : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
 }
 
-hipError_t launch_raymarch(const RayKernelArgs &a, const void *volume, uint32_t bpv, const float *tf,
+hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bpv, const float *tf,
                            const uint32_t *esl, void *out, hipStream_t stream) {
-	return bpv == 1 ? launch_bpv<1>(a, volume, tf, esl, out, stream) : launch_bpv<2>(a, volume, tf, esl, out, stream);
+	return bpv == 1 ? launch_bpv<1>(a, linear, bricked, tf, esl, out, stream) : launch_bpv<2>(a, linear, bricked, tf, esl, out, stream);
 }
 
 // ---- linear -> bricked copy ------------------------------------------------------------------------------------------

@@ -49,15 +49,24 @@ class FrameSplit:
 
     def gather(self, local, staging=None, dst=0, group=None):
         """Collects every rank's bands on `dst`; returns the assembled [H, W, 4] frame there, None elsewhere."""
-        if self.world == 1:
-            return local[: self.height]
+        work, finish = self.gather_async(local, staging, dst, group)
+        if work is not None:
+            work.wait()
+        return finish()
+
+    def gather_async(self, local, staging=None, dst=0, group=None):
+        """Starts the gather (it runs on the backend's own stream, ordered after the work already queued on the current
+        stream) and returns (work, finish): `work.wait()` orders the current stream after the transfer, `finish()` then
+        returns the assembled frame on `dst` (None elsewhere).  Lets frame i+1 render while frame i is collected."""
+        if self.world == 1 and not dist.is_initialized():
+            return None, lambda: local[: self.height]
         if self.rank == dst:
             if staging is None:
                 staging = self.staging_buffer(local.device)
-            dist.gather(local, gather_list=[staging[r] for r in range(self.world)], dst=dst, group=group)
-            return self.assemble(staging)
-        dist.gather(local, gather_list=None, dst=dst, group=group)
-        return None
+            work = dist.gather(local, gather_list=[staging[r] for r in range(self.world)], dst=dst, group=group, async_op=True)
+            return work, lambda: self.assemble(staging)
+        work = dist.gather(local, gather_list=None, dst=dst, group=group, async_op=True)
+        return work, lambda: None
 
 
 def default_band_rows(height, world):
