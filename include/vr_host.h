@@ -46,6 +46,17 @@ void vr_host_raycaster_reset_ray_step(void);
 int vr_host_raycaster_get(vr_params *params, float *tf_premult_out /*128x4*/, uint32_t *esl_bits_out /*1024*/,
                           uint8_t *minmax_pairs_out /*32768x2*/, float *base_rgba_out /*128x4*/);
 
+/* ---- ModelBase + the volume file codec (reference ModelBase.cpp, ddsbase.cpp) ----
+ * ModelBase::load_model: ".pvm" (plain or DDS-compressed, 8 or 16 bit -> quantised to 8 bit) or ".raw" (dimensions from
+ * vr_host_set_raw_dims beforehand instead of the reference's stdin prompt).  Returns 0 ok / 1 failure like the reference.
+ * The decoded volume stays owned by the library until the next load. */
+int vr_host_load_model(const char *file_name, uint32_t dims_out[3]);
+void vr_host_set_raw_dims(uint32_t width, uint32_t height, uint32_t depth, uint32_t components);
+const uint8_t *vr_host_model_voxels(void);                       /* ModelBase::volume.data (NULL before a load) */
+void vr_host_model_histogram(float out256[256]);                 /* ModelBase::histogram */
+/* quantize(): width*height*depth big-endian 16-bit samples -> 8 bit (linear = 0: the non-linear mapping load_model uses) */
+int vr_host_quantize(const uint8_t *data16, uint32_t width, uint32_t height, uint32_t depth, int linear, uint8_t *out8);
+
 /* ---- one frame through the C++ mirror: HipRenderer(RaycasterBase::raycaster).render_volume(host buffer) ----
  * Uses the volume previously given to vr_host_raycaster_set_volume (voxels must still be valid) and `view`.
  * Returns what render_volume returns (0 / 1). */

@@ -119,6 +119,16 @@ int volr_ref_render(unsigned int w, unsigned int h, const float *view15, int per
 	return rc;
 }
 
+// ModelBase::histogram (ModelBase.cpp:19-33) of the loaded model
+void volr_ref_get_histogram(float *out256) { memcpy(out256, ModelBase::histogram, 256 * sizeof(float)); }
+
+// ddsbase.cpp quantize(): 16-bit big-endian samples -> 8 bit; the reference frees its input unless nofree
+void volr_ref_quantize(const unsigned char *data16, unsigned int w, unsigned int h, unsigned int d, int linear, unsigned char *out8) {
+	unsigned char *q = quantize((unsigned char *) data16, w, h, d, linear != 0, TRUE);
+	memcpy(out8, q, (size_t) w * h * d);
+	free(q);
+}
+
 // sizeof checks for the record (160 / 32 / 68 on LP64)
 void volr_ref_sizes(unsigned int *out3) {
 	out3[0] = sizeof(Raycaster); out3[1] = sizeof(Model); out3[2] = sizeof(View);

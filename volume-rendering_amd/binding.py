@@ -100,6 +100,11 @@ def lib():
         "vr_host_raycaster_reset_ray_step": (None, []),
         "vr_host_raycaster_get": (C.c_int, [P(VrParams), vp, vp, vp, vp]),
         "vr_host_render_frame": (C.c_int, [C.c_int, u32, P(VrView), vp]),
+        "vr_host_load_model": (C.c_int, [C.c_char_p, P(u32)]),
+        "vr_host_set_raw_dims": (None, [u32, u32, u32, u32]),
+        "vr_host_model_voxels": (vp, []),
+        "vr_host_model_histogram": (None, [f32p]),
+        "vr_host_quantize": (C.c_int, [vp, u32, u32, u32, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)      # AttributeError here = the library does not export what the headers declare

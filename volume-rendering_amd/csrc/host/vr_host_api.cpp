@@ -2,6 +2,7 @@
 #include "../../../include/vr_host.h"
 #include "RaycasterBase.h"
 #include "ViewBase.h"
+#include "ModelBase.h"
 
 #include <string.h>
 
@@ -96,6 +97,26 @@ int vr_host_raycaster_get(vr_params *p, float *tf_out, uint32_t *esl_out, uint8_
 	if (esl_out) memcpy(esl_out, r.esl_volume, ESL_VOLUME_SIZE * sizeof(esl_type));
 	if (minmax_out) memcpy(minmax_out, RaycasterBase::block_min_max(), ESL_VOLUME_DIMS * ESL_VOLUME_DIMS * ESL_VOLUME_DIMS * 2);
 	if (base_out) memcpy(base_out, RaycasterBase::base_transfer_fn, TF_SIZE * sizeof(float4));
+	return VR_OK;
+}
+
+int vr_host_load_model(const char *file_name, uint32_t dims_out[3]) {
+	if (file_name == nullptr) return 1;
+	const int rc = ModelBase::load_model(file_name);
+	if (rc == 0 && dims_out) {
+		dims_out[0] = ModelBase::volume.dims.x; dims_out[1] = ModelBase::volume.dims.y; dims_out[2] = ModelBase::volume.dims.z;
+	}
+	return rc;
+}
+
+void vr_host_set_raw_dims(uint32_t w, uint32_t h, uint32_t d, uint32_t components) { ModelBase::set_raw_dims(w, h, d, components); }
+const uint8_t *vr_host_model_voxels(void) { return ModelBase::volume.data; }
+void vr_host_model_histogram(float out[256]) { memcpy(out, ModelBase::histogram, sizeof ModelBase::histogram); }
+
+int vr_host_quantize(const uint8_t *data16, uint32_t w, uint32_t h, uint32_t d, int linear, uint8_t *out8) {
+	if (data16 == nullptr || out8 == nullptr || w == 0 || h == 0 || d == 0) return VR_ERR_INVALID;
+	const std::vector<uint8_t> q = quantize_16_to_8(data16, w, h, d, linear != 0);
+	memcpy(out8, q.data(), q.size());
 	return VR_OK;
 }
 
