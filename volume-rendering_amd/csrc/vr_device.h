@@ -26,6 +26,7 @@ struct RayKernelArgs {
 	float    lh_x,   lh_y,   lh_z;     // 0.01f * half: texel-space length of the shading offset (GPURenderer4.cu:43-46)
 	float    tf_scale;                 // 128/255 (u8) or 128/65535 (u16): raw interpolated voxel -> TF texel coordinate + 0.5
 	float    kd_scaled;                // light_kd / 255 (u8) or / 65535 (u16)
+	float    tf_zero_below;            // entries 0..tf_zero_below of the premultiplied TF are exactly (0,0,0,0); -1 if entry 0 is not
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
@@ -48,9 +49,27 @@ constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
 // 3-bit Morton dilation: bit i of v moves to bit 3*i
 __host__ __device__ inline uint32_t dilate3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }
-// element offset inside a brick (z lowest, then x, then y)
+__host__ __device__ inline uint32_t undilate3(uint32_t v) { return (v & 1u) | ((v >> 2) & 2u) | ((v >> 4) & 4u); }
+// which interleave slot (bit 0, 1 or 2 of every 3-bit group) each axis occupies inside a brick
+#ifndef VR_MORTON_PERM
+#define VR_MORTON_PERM 5
+#endif
+#if VR_MORTON_PERM == 0
+constexpr uint32_t kSlotX = 1, kSlotY = 2, kSlotZ = 0;
+#elif VR_MORTON_PERM == 1
+constexpr uint32_t kSlotX = 0, kSlotY = 1, kSlotZ = 2;
+#elif VR_MORTON_PERM == 2
+constexpr uint32_t kSlotX = 2, kSlotY = 0, kSlotZ = 1;
+#elif VR_MORTON_PERM == 3
+constexpr uint32_t kSlotX = 0, kSlotY = 2, kSlotZ = 1;
+#elif VR_MORTON_PERM == 4
+constexpr uint32_t kSlotX = 1, kSlotY = 0, kSlotZ = 2;
+#elif VR_MORTON_PERM == 5
+constexpr uint32_t kSlotX = 2, kSlotY = 1, kSlotZ = 0;
+#endif
+// element offset inside a brick
 __host__ __device__ inline uint32_t brick_local(uint32_t lx, uint32_t ly, uint32_t lz) {
-	return dilate3(lz) | (dilate3(lx) << 1) | (dilate3(ly) << 2);
+	return (dilate3(lz) << kSlotZ) | (dilate3(lx) << kSlotX) | (dilate3(ly) << kSlotY);
 }
 
 // Volume resident in HBM: the reference's linear layout (x fastest, then y, then z — ModelBase.h:18-22) followed by

@@ -34,6 +34,7 @@ struct vr_ctx {
 	void *fb = nullptr; size_t fb_bytes = 0;
 	// transfer function + ESL
 	float *tf = nullptr; uint32_t *esl = nullptr; bool tf_set = false;
+	float tf_zero_below = -1.0f;            // leading all-zero entries of the resident TF (exact transparent-sample shortcut)
 	// volume
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
 	void *vol_bricked = nullptr;            // TRILINEAR copy in the bricked layout (vr_device.h), built by set_volume
@@ -115,6 +116,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.lh_x = 0.01f * a.half_x; a.lh_y = 0.01f * a.half_y; a.lh_z = 0.01f * a.half_z;
 	a.tf_scale = c->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
 	a.kd_scaled = p->light_kd * (c->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
+	a.tf_zero_below = c->tf_zero_below;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
@@ -241,6 +243,11 @@ int vr_hip_set_transfer_fn(vr_ctx *c, const float *tf, const uint32_t *esl) {
 	VR_TRY(c, hipSetDevice(c->device));
 	VR_TRY(c, hipMemcpy(c->tf, tf, VR_TF_SIZE * 4 * sizeof(float), hipMemcpyHostToDevice));
 	VR_TRY(c, hipMemcpy(c->esl, esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t), hipMemcpyHostToDevice));
+	int zero = -1;
+	while (zero + 1 < VR_TF_SIZE && tf[4 * (zero + 1)] == 0.0f && tf[4 * (zero + 1) + 1] == 0.0f && tf[4 * (zero + 1) + 2] == 0.0f &&
+	       tf[4 * (zero + 1) + 3] == 0.0f)
+		zero++;
+	c->tf_zero_below = (float) zero;
 	c->tf_set = true;
 	return VR_OK;
 }

@@ -126,9 +126,9 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		if (ADDR == kAddrWide) {
 			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
 			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
-			const uint32_t lxy = (dilate3(ix & 7u) << 1) | (dilate3(iy & 7u) << 2);
-			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz & 7u))) * kElem;
-			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | dilate3(iz1 & 7u))) * kElem;
+			const uint32_t lxy = (dilate3(ix & 7u) << kSlotX) | (dilate3(iy & 7u) << kSlotY);
+			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz & 7u) << kSlotZ))) * kElem;
+			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz1 & 7u) << kSlotZ))) * kElem;
 		} else {
 			// per-axis offset tables in LDS at FIXED positions (filled once per workgroup): brick base + Morton-dilated
 			// in-brick offset, split by axis; the z table holds {offset(z), offset(min(z+1, Z-1))} pairs so one ds_read_b64
@@ -298,11 +298,11 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			const uint32_t row = a.nbx * kBrickPitch, slab = a.nby * row;
 			for (uint32_t i = t; i < nz; i += kThreads) {
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
-				lut[2 * i]     = ((i >> 3) * slab + dilate3(i & 7u)) * scale;
-				lut[2 * i + 1] = ((j >> 3) * slab + dilate3(j & 7u)) * scale;
+				lut[2 * i]     = ((i >> 3) * slab + (dilate3(i & 7u) << kSlotZ)) * scale;
+				lut[2 * i + 1] = ((j >> 3) * slab + (dilate3(j & 7u) << kSlotZ)) * scale;
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[kLutX + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << 1)) * scale;
-			for (uint32_t i = t; i < ny; i += kThreads) lut[kLutY + i] = ((i >> 3) * row + (dilate3(i & 7u) << 2)) * scale;
+			for (uint32_t i = t; i < nx; i += kThreads) lut[kLutX + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << kSlotX)) * scale;
+			for (uint32_t i = t; i < ny; i += kThreads) lut[kLutY + i] = ((i >> 3) * row + (dilate3(i & 7u) << kSlotY)) * scale;
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -330,9 +330,23 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	//    4x4-pixel block (not two 8-pixel rows): the vector L1 coalesces per 16-lane group, and a compact block keeps the
 	//    group's samples inside the fewest 32-byte sectors whatever the view direction.
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#ifndef VR_LANE_GROUP
+#define VR_LANE_GROUP 0
+#endif
+#if VR_LANE_GROUP == 0          // 16-lane group = 4x4 pixels, wave = 2x2 groups = 8x8
 	const uint32_t qd = lane >> 4;
-	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + (qd & 1u) * 4u + (lane & 3u);
-	const uint32_t ly = tile_y * 16u + (wave >> 2) * 8u + (qd >> 1) * 4u + ((lane >> 2) & 3u);
+	const uint32_t wx = (qd & 1u) * 4u + (lane & 3u), wy = (qd >> 1) * 4u + ((lane >> 2) & 3u);
+#elif VR_LANE_GROUP == 1        // row major 8x8: group = 8x2 pixels
+	const uint32_t wx = lane & 7u, wy = lane >> 3;
+#elif VR_LANE_GROUP == 2        // group = 2x8 pixels (column pairs)
+	const uint32_t qd = lane >> 4;
+	const uint32_t wx = qd * 2u + (lane & 1u), wy = (lane >> 1) & 7u;
+#elif VR_LANE_GROUP == 3        // 2x2 quads inside 4x4 groups (Z-order of lanes)
+	const uint32_t qd = lane >> 4;
+	const uint32_t wx = (qd & 1u) * 4u + ((lane >> 2) & 1u) * 2u + (lane & 1u), wy = (qd >> 1) * 4u + ((lane >> 3) & 1u) * 2u + ((lane >> 1) & 1u);
+#endif
+	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + wx;
+	const uint32_t ly = tile_y * 16u + (wave >> 2) * 8u + wy;
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
@@ -440,29 +454,37 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			nxt = issue(kn);
 			__builtin_amdgcn_sched_barrier(0);
 			const float raw = tri_resolve<BPV, LAYOUT>(cur);                                       // GPURenderer4.cu:76
-			f4 c;
-			{                                                                                      // GPURenderer4.cu:77 filtered TF
-				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-				const uint32_t i = (uint32_t) (int) tb;
-				const float w = __builtin_amdgcn_fractf(tb);
-				const f4 c0 = lds.tf[i], dc = lds.dtf[i];
-				c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
-				c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
+			// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
+			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+			// Exact shortcut, decided per wave: entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
+			// default TF is zero below 10 % density), so a sample with tb < tf_zero_below has colour (0,0,0,0), is never
+			// shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.  If that holds for every live lane the wave
+			// skips the LDS lookups, the shading test and the composite.
+			if (__builtin_amdgcn_ballot_w64(alive && !(tb < a.tf_zero_below)) != 0ull) {
+				f4 c;
+				{
+					const uint32_t i = (uint32_t) (int) tb;
+					const float w = __builtin_amdgcn_fractf(tb);
+					const f4 c0 = lds.tf[i], dc = lds.dtf[i];
+					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
+					c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
+				}
+				if (alive && c.w > 0.05f && lit) {                                                 // GPURenderer4.cu:41-51 shade_texture
+					const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
+					const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
+					const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
+					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
+					const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
+					                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
+					const float diffuse = (raw_l - raw) * a.kd_scaled;
+					c.x += diffuse; c.y += diffuse; c.z += diffuse;
+				}
+				const float t = alive ? 1 - acc.w : 0.0f;
+				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
+				acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
+				alive = alive && !(acc.w > threshold);                  // ERT (CPURenderer.cpp:35-36)
 			}
-			if (alive && c.w > 0.05f && lit) {                                                     // GPURenderer4.cu:41-51 shade_texture
-				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
-				const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
-				const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
-				const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-				const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
-				                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
-				const float diffuse = (raw_l - raw) * a.kd_scaled;
-				c.x += diffuse; c.y += diffuse; c.z += diffuse;
-			}
-			const float t = alive ? 1 - acc.w : 0.0f;
-			acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
-			acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
-			alive = alive && !(acc.w > threshold) && (kn <= ky);       // ERT (CPURenderer.cpp:35-36), then the loop condition
+			alive = alive && (kn <= ky);                                // the loop condition
 			kx = kn;
 		};
 		TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
@@ -532,10 +554,8 @@ void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint3
 	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
 		const uint64_t brick = o / kBrickPitch;
 		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
-		// undo the Morton order: bits 0,3,6 -> z, 1,4,7 -> x, 2,5,8 -> y
-		const uint32_t lz = (local & 1u) | ((local >> 2) & 2u) | ((local >> 4) & 4u);
-		const uint32_t lx = ((local >> 1) & 1u) | ((local >> 3) & 2u) | ((local >> 5) & 4u);
-		const uint32_t ly = ((local >> 2) & 1u) | ((local >> 4) & 2u) | ((local >> 6) & 4u);
+		// undo the Morton order
+		const uint32_t lz = undilate3(local >> kSlotZ), lx = undilate3(local >> kSlotX), ly = undilate3(local >> kSlotY);
 		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
 		const uint32_t by = br / nbx, bx = br - by * nbx;
 		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
