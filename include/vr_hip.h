@@ -125,6 +125,10 @@ int vr_hip_set_volume_device(vr_ctx *ctx, const void *dev_voxels, uint32_t dim_x
  * resident volume (rebuilds or drops the bricked copy) and for later set_volume calls.  No reference counterpart. */
 int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
 
+/* Testing aid: force != 0 makes every later frame use the 64-bit index arithmetic that volumes beyond 1024^3 / 4 GiB need
+ * (BASELINE config 5), so that path can be parity-tested on small volumes.  Images are identical either way. */
+int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
+
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
  *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.

@@ -111,6 +111,33 @@ def test_u16_volume_matches_oracle(vr, gpu, golden, oracle):
     assert np.array_equal(out16, golden.frame(case))
 
 
+def test_wide_addressing_path(vr, gpu, golden, oracle):
+    """The 64-bit index path of volumes beyond 1024^3 (BASELINE config 5), forced on small volumes: same images.
+    u8 and u16, both layouts, both sampling modes."""
+    vox8 = golden.voxels("blob_40x24x56")
+    st = golden.volume_state("blob_40x24x56")
+    gpu.set_transfer_fn(st["tf"], st["esl"])
+    gpu.set_window_buffer(256, 256)
+    cases = [c for c in golden.cases(True) if c["volume"] == "blob_40x24x56"][:3]
+    try:
+        for vox in (vox8, vox8.astype(np.uint16) * 257):
+            gpu.set_volume(vox)
+            for layout in (vr.LAYOUT_BRICKED, vr.LAYOUT_LINEAR):
+                gpu.set_layout(layout)
+                for case in cases:
+                    for mode in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+                        p = golden.params(case, mode)
+                        gpu.set_wide_addressing(False)
+                        narrow = gpu.render_volume(p)
+                        gpu.set_wide_addressing(True)
+                        wide = gpu.render_volume(p)
+                        assert np.array_equal(narrow, wide), (vox.dtype, layout, case["label"], mode)
+                        assert np.array_equal(wide, oracle.render(p, vox, st["tf"], st["esl"])), (vox.dtype, layout, case["label"], mode)
+    finally:
+        gpu.set_wide_addressing(False)
+        gpu.set_layout(vr.LAYOUT_BRICKED)
+
+
 def test_partition_concatenates_to_the_whole_frame(vr, gpu, golden):
     """SURVEY §8e correctness check: n ranks' bands assembled == 1-rank frame, byte for byte."""
     from importlib import import_module

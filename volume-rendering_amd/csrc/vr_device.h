@@ -29,6 +29,7 @@ struct RayKernelArgs {
 	float    tf_zero_below;            // entries 0..tf_zero_below of the premultiplied TF are exactly (0,0,0,0); -1 if entry 0 is not
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
+	uint32_t force_wide;               // testing aid: take the 64-bit index path even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
 

@@ -39,6 +39,7 @@ struct vr_ctx {
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
 	void *vol_bricked = nullptr;            // TRILINEAR copy in the bricked layout (vr_device.h), built by set_volume
 	uint32_t layout = VR_LAYOUT_BRICKED;
+	uint32_t force_wide = 0;
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -117,6 +118,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.tf_scale = c->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
 	a.kd_scaled = p->light_kd * (c->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
 	a.tf_zero_below = c->tf_zero_below;
+	a.force_wide = c->force_wide;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
@@ -281,6 +283,12 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 	VR_TRY(c, hipDeviceSynchronize());           // a frame may still be reading the copy we are about to drop
 	c->layout = layout;
 	return finalize_volume(c);
+}
+
+int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	c->force_wide = force ? 1u : 0u;
+	return VR_OK;
 }
 
 int vr_hip_render_device(vr_ctx *c, const vr_params *p, void *dev_rgba, void *stream) {

@@ -288,6 +288,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	constexpr bool kUseLut = LAYOUT == kLayoutBricked && ADDR != kAddrWide;
 	__shared__ LdsTables lds;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[kUseLut ? kLutWords : 4];
+#ifdef VR_LDS_PAD          // tuning aid: occupy extra LDS to lower the number of resident workgroups per CU
+	__shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
+	if (a.dim_x == 0xffffffffu) lds_pad[threadIdx.x] = 1;
+#endif
 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
@@ -516,9 +520,9 @@ template <int BPV>
 static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
                              const uint32_t *esl, void *out, hipStream_t stream) {
 	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
-	if (bricked != nullptr) {
+	if (bricked != nullptr && !(nearest && a.force_wide)) {
 		const uint64_t elems = bricked_elems(a.dim_x, a.dim_y, a.dim_z);
-		const bool lut_ok = a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
+		const bool lut_ok = !a.force_wide && a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
 		if (lut_ok && elems * 4 * BPV <= (1ull << 32))
 			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream)
 			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
@@ -529,7 +533,7 @@ static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const v
 		}
 	}
 	// the reference's linear array; 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12)
-	const bool wide = ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);
+	const bool wide = a.force_wide || ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);
 	if (nearest)
 		return wide ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
 		            : launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);

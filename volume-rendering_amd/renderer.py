@@ -70,6 +70,10 @@ class HipRenderer:
         """LAYOUT_LINEAR | LAYOUT_BRICKED for the TRILINEAR copy of the volume (images are identical, speed is not)."""
         self._check(self._L.vr_hip_set_layout(self._ctx, int(layout)), "set_layout")
 
+    def set_wide_addressing(self, force):
+        """Testing aid: take the 64-bit index path (volumes > 1024^3) regardless of the volume size."""
+        self._check(self._L.vr_hip_set_wide_addressing(self._ctx, int(bool(force))), "set_wide_addressing")
+
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
         k = {"shell": 0, "noise": 1}[kind]
