@@ -124,6 +124,7 @@ def test_config3_512_at_1080p(vr, gpu, oracle):
     scene.set_modes(ray_threshold=1.0)
     full = gpu.render_volume(scene.frame_params(view, vr.SAMPLE_NEAREST))
     assert compare_frames(full, on)[1] <= 14          # (1 - 0.95) * 256 + rounding: ERT may only drop the last 5 % of opacity
+    scene.set_modes(esl=True, ray_threshold=0.95)
 
 
 def test_config5_2048_u16_at_4096(vr, gpu, oracle):

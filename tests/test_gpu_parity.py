@@ -181,6 +181,7 @@ def test_cpp_renderer_mirror(vr, gpu, golden):
     """The host C++ mirror: RaycasterBase::reset_transfer_fn/set_volume -> HipRenderer(raycaster).render_volume()."""
     vox = golden.voxels("bucky")
     scene = vr.Scene().set_volume(voxels=vox)
+    scene.set_modes(esl=True, ray_threshold=0.95, light_kd=0.6)     # RaycasterBase state is process-global, like the reference's
     st = golden.volume_state("bucky")
     assert np.array_equal(scene.tf, st["tf"]) and np.array_equal(scene.esl, st["esl"])
     for label in ("bench256_view2_default", "bench256_view7_default"):

@@ -413,11 +413,20 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const bool lit = kd > 0.01f;
 	const float threshold = a.p.ray_threshold;
 	if (SAMPLING == VR_SAMPLE_NEAREST) {
-		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {           // wave-uniform exit: every lane terminated (ERT) or left the cube
-			if (alive) {
-				const uint32_t s = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pt);
-				f4 cur = lds.tf[(BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO];         // CPURenderer.cpp:31
-				if (cur.w > 0.05f && lit) {                                       // RaycasterBase.h:87-98 shade
+		// Same loop shape as the TRILINEAR branch below (prefetch of sample i+1, finished lanes composited with weight 0,
+		// per-wave transparent-sample shortcut, two samples per exit vote); the arithmetic is the reference's, unfused:
+		// acc + cur * 0 == acc exactly, and map_float_int clamps every index, so speculative fetches stay in bounds.
+		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
+		auto step_sample = [&](const uint32_t &cur_s, uint32_t &nxt_s) {
+			const float kn = kx + step;
+			const f3 pn = march_point<SAMPLING>(origin, dir, kn);
+			nxt_s = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pn);
+			__builtin_amdgcn_sched_barrier(0);
+			const uint32_t s = cur_s;
+			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
+			if (__builtin_amdgcn_ballot_w64(alive && (int) idx > tf_zero_idx) != 0ull) {
+				f4 cur = lds.tf[idx];
+				if (alive && cur.w > 0.05f && lit) {                                              // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
 					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
@@ -427,17 +436,19 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					float diffuse = (sl - (float) s / raw) * kd;
 					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				}
-				const float t = 1 - acc.w;                                        // CPURenderer.cpp:34
+				const float t = alive ? 1 - acc.w : 0.0f;                                         // CPURenderer.cpp:34
 				acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
 				acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
-				if (acc.w > threshold) {            // early ray termination (CPURenderer.cpp:35-36)
-					alive = false;
-				} else {
-					kx += step;
-					pt = march_point<SAMPLING>(origin, dir, kx);
-					alive = kx <= ky;
-				}
+				alive = alive && !(acc.w > threshold);                                            // CPURenderer.cpp:35-36
 			}
+			alive = alive && (kn <= ky);
+			kx = kn;
+			pt = pn;
+		};
+		uint32_t sa = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pt), sb = 0;
+		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+			step_sample(sa, sb);
+			step_sample(sb, sa);
 		}
 	} else {
 		// texel-space ray: coordinate = fma(k, A, B) (see oracle/vr_oracle.c axis_setup)
