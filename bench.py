@@ -176,21 +176,32 @@ def main():
     params = [split.apply(scene.frame_params(v, sampling)) for v in views]
     stream = torch.cuda.current_stream().cuda_stream
 
+    # the assembled frame (what a display or an encoder would consume) lives on rank 0
+    final = torch.empty((H, W, 4), dtype=torch.uint8, device=device) if (rank == 0 and distributed) else None
+
+    def retire(slot):
+        """Frame in `slot` has been gathered: order the current stream after the transfer and de-interleave the bands
+        into the final frame (one strided copy kernel on rank 0)."""
+        if pending[slot] is None:
+            return
+        work, finish = pending[slot]
+        work.wait()
+        frame = finish()
+        if final is not None and frame is not None:
+            final.copy_(frame)
+        pending[slot] = None
+
     def step(i):
         slot = i & 1
-        if pending[slot] is not None:
-            pending[slot][0].wait()                 # the buffer pair of frame i-2 is free again
-            pending[slot] = None
+        retire(slot)                                # the buffer pair of frame i-2 is free again
         r.render_volume_device(params[i % 8], local[slot].data_ptr(), stream)
         work, finish = split.gather_async(local[slot], staging[slot])
         if work is not None:
             pending[slot] = (work, finish)
 
     def fence():
-        for slot in range(2):
-            if pending[slot] is not None:
-                pending[slot][0].wait()
-                pending[slot] = None
+        retire(0)
+        retire(1)
         if distributed:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
