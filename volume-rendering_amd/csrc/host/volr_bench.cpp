@@ -11,9 +11,9 @@
 #include <vector>
 
 #include "ModelBase.h"
-#include "Profiler.h"
+#include "frame_stats.h"
 #include "RaycasterBase.h"
-#include "ViewBase.h"
+#include "camera.h"
 
 using namespace volr;
 

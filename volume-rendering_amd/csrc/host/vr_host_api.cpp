@@ -1,7 +1,7 @@
 // vr_host_api.cpp — extern "C" wrappers of include/vr_host.h around the host mirror classes.
 #include "../../../include/vr_host.h"
 #include "RaycasterBase.h"
-#include "ViewBase.h"
+#include "camera.h"
 #include "ModelBase.h"
 
 #include <string.h>
