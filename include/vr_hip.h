@@ -125,8 +125,9 @@ int vr_hip_set_volume_device(vr_ctx *ctx, const void *dev_voxels, uint32_t dim_x
  * resident volume (rebuilds or drops the bricked copy) and for later set_volume calls.  No reference counterpart. */
 int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
 
-/* Testing aid: force != 0 makes every later frame use the 64-bit index arithmetic that volumes beyond 1024^3 / 4 GiB need
- * (BASELINE config 5), so that path can be parity-tested on small volumes.  Images are identical either way. */
+/* Testing aid: makes every later frame use one of the two 64-bit addressing paths that volumes beyond 1024^3 / 4 GiB need
+ * (BASELINE config 5), so that they can be parity-tested on small volumes: 1 = index arithmetic without tables (dims above
+ * 2048), 2 = address tables with 64-bit z offsets (dims up to 2048), 0 = automatic.  Images are identical either way. */
 int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
 
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----

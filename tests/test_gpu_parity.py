@@ -129,9 +129,10 @@ def test_wide_addressing_path(vr, gpu, golden, oracle):
                         p = golden.params(case, mode)
                         gpu.set_wide_addressing(False)
                         narrow = gpu.render_volume(p)
-                        gpu.set_wide_addressing(True)
-                        wide = gpu.render_volume(p)
-                        assert np.array_equal(narrow, wide), (vox.dtype, layout, case["label"], mode)
+                        for force in (1, 2):       # arithmetic 64-bit path, table path with 64-bit z offsets
+                            gpu.set_wide_addressing(force)
+                            wide = gpu.render_volume(p)
+                            assert np.array_equal(narrow, wide), (vox.dtype, layout, case["label"], mode, force)
                         assert np.array_equal(wide, oracle.render(p, vox, st["tf"], st["esl"])), (vox.dtype, layout, case["label"], mode)
     finally:
         gpu.set_wide_addressing(False)

@@ -18,7 +18,7 @@ constexpr uint32_t kMaxRaySteps = 1u << 22;
 struct RayKernelArgs {
 	vr_params p;
 	uint32_t dim_x, dim_y, dim_z;      // Model::dims (ModelBase.h:13), widened
-	uint32_t tiles_x, tiles_y;         // 32x16-pixel workgroup tiles over the out_width x out_rows output
+	uint32_t tiles_x, tiles_y;         // workgroup tiles (32x16 or 32x32 pixels) over the output; filled in at launch
 	uint64_t stride_y, stride_z;       // voxel strides (elements): dim_x, dim_x*dim_y
 	float    half_x, half_y, half_z;   // 0.5f * dim  (TRILINEAR coordinate: xb = fma(pos, half, half - 0.5))
 	float    off_x,  off_y,  off_z;    // 0.5f * dim - 0.5f
@@ -29,7 +29,7 @@ struct RayKernelArgs {
 	float    tf_zero_below;            // entries 0..tf_zero_below of the premultiplied TF are exactly (0,0,0,0); -1 if entry 0 is not
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
-	uint32_t force_wide;               // testing aid: take the 64-bit index path even for small volumes
+	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
 

@@ -109,7 +109,6 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	memset(&a, 0, sizeof a);
 	a.p = *p;
 	a.dim_x = c->dim[0]; a.dim_y = c->dim[1]; a.dim_z = c->dim[2];
-	a.tiles_x = (p->out_width + 31u) / 32u; a.tiles_y = (p->out_rows + 15u) / 16u;
 	a.stride_y = c->dim[0]; a.stride_z = (uint64_t) c->dim[0] * c->dim[1];
 	a.half_x = 0.5f * (float) c->dim[0]; a.half_y = 0.5f * (float) c->dim[1]; a.half_z = 0.5f * (float) c->dim[2];
 	a.off_x = a.half_x - 0.5f; a.off_y = a.half_y - 0.5f; a.off_z = a.half_z - 0.5f;
@@ -287,7 +286,7 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 
 int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	c->force_wide = force ? 1u : 0u;
+	c->force_wide = force;                       // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
 	return VR_OK;
 }
 

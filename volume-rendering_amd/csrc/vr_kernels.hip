@@ -45,16 +45,20 @@ struct __attribute__((aligned(16))) LdsTables {
 	uint32_t esl[VR_ESL_VOLUME_SIZE];
 };
 
-// Brick address tables (bricked TRILINEAR, dims <= kLutMaxDim): fixed LDS positions so the per-sample lookups are one
-// shift + one ds_read with an immediate offset each.  z pairs first (8-byte aligned), then x, then y.
-constexpr uint32_t kLutMaxDim = 1024;
-constexpr uint32_t kLutX = 2 * kLutMaxDim, kLutY = 3 * kLutMaxDim, kLutWords = 4 * kLutMaxDim;
-
 // How voxel addresses are formed (template parameter ADDR):
-//   kAddr32  : 32-bit BYTE offsets from a scalar base (global_load ... v_off, s[base:base+1]); volume copy < 4 GiB
-//   kAddrElem: 32-bit ELEMENT indices, 64-bit address arithmetic (bricked layout up to 2^32 elements)
-//   kAddrWide: full 64-bit index arithmetic, no LDS address tables (anything larger, e.g. 2048^3)
-enum : int { kAddr32 = 0, kAddrElem = 1, kAddrWide = 2 };
+//   kAddr32   : 32-bit BYTE offsets from a scalar base (global_load ... v_off, s[base:base+1]); brick copy <= 4 GiB, dims <=
+//               1024; per-axis offset tables in LDS, 512-thread workgroups (8 waves = 32x16 pixels)
+//   kAddrLut64: dims <= 2048 and any size (BASELINE config 5: 2048^3 u16 = 64 GiB of bricks): the z table holds 64-bit byte
+//               offsets, x and y 32-bit offsets inside one brick slab; 1024-thread workgroups (16 waves = 32x32 pixels) so
+//               that two workgroups per CU still reach the 32-wave limit next to 56 KiB of tables each
+//   kAddrWide : full 64-bit index arithmetic, no tables (anything larger; also the linear layout beyond 4 GiB)
+enum : int { kAddr32 = 0, kAddrLut64 = 1, kAddrWide = 2 };
+
+// Brick address tables at FIXED LDS positions, so a lookup is one shift + one ds_read with an immediate offset:
+// z entries first ({offset(z), offset(min(z+1, Z-1))} pairs: one ds_read_b64 / b128 serves both slices), then x, then y.
+template <int ADDR> struct LutCfg          { static constexpr uint32_t max_dim = 0,    z_words = 0, x_at = 0,    y_at = 0,     words = 4,     threads = 512; };
+template <> struct LutCfg<kAddr32>         { static constexpr uint32_t max_dim = 1024, z_words = 2, x_at = 2048, y_at = 3072,  words = 4096,  threads = 512; };
+template <> struct LutCfg<kAddrLut64>      { static constexpr uint32_t max_dim = 2048, z_words = 4, x_at = 8192, y_at = 10240, words = 12288, threads = 1024; };
 
 template <int BPV> struct VoxelT;
 template <> struct VoxelT<1> { typedef uint8_t type; };
@@ -70,9 +74,17 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
                                                 uint32_t ix, uint32_t iy, uint32_t iz) {
 	typedef typename VoxelT<BPV>::type V;
 	if (LAYOUT == kLayoutBricked) {
-		const uint32_t off = lut[2 * iz] + lut[kLutX + ix] + lut[kLutY + iy];      // byte offset (kAddr32 tables)
-		if (BPV == 1) return *(const uint32_t *) ((const uint8_t *) vol + off) & 0xffu;
-		return *(const uint32_t *) ((const uint8_t *) vol + off) & 0xffffu;
+		typedef LutCfg<ADDR> L;
+		const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
+		const uint8_t *q;
+		if (ADDR == kAddr32) {
+			q = (const uint8_t *) vol + (exy + lut[L::z_words * iz]);
+		} else {
+			const uint2 z = *(const uint2 *) (lut + L::z_words * iz);
+			q = (const uint8_t *) vol + ((((uint64_t) z.y) << 32 | z.x) + exy);
+		}
+		if (BPV == 1) return *(const uint32_t *) q & 0xffu;
+		return *(const uint32_t *) q & 0xffffu;
 	}
 	if (ADDR == kAddrWide) {
 		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
@@ -130,17 +142,17 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz & 7u) << kSlotZ))) * kElem;
 			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz1 & 7u) << kSlotZ))) * kElem;
 		} else {
-			// per-axis offset tables in LDS at FIXED positions (filled once per workgroup): brick base + Morton-dilated
-			// in-brick offset, split by axis; the z table holds {offset(z), offset(min(z+1, Z-1))} pairs so one ds_read_b64
-			// serves both slices.  kAddr32: the tables hold byte offsets, kAddrElem: element indices.
-			const uint2 zz = *(const uint2 *) (lut + 2 * iz);
-			const uint32_t exy = lut[kLutX + ix] + lut[kLutY + iy];
+			// per-axis byte-offset tables in LDS (LutCfg): brick base + Morton-dilated in-brick offset, split by axis
+			typedef LutCfg<ADDR> L;
+			const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
 			if (ADDR == kAddr32) {
+				const uint2 zz = *(const uint2 *) (lut + L::z_words * iz);
 				q0 = (const uint8_t *) vol + (exy + zz.x);
 				q1 = (const uint8_t *) vol + (exy + zz.y);
 			} else {
-				q0 = (const uint8_t *) vol + (uint64_t) (exy + zz.x) * kElem;
-				q1 = (const uint8_t *) vol + (uint64_t) (exy + zz.y) * kElem;
+				const uint4 zz = *(const uint4 *) (lut + L::z_words * iz);
+				q0 = (const uint8_t *) vol + ((((uint64_t) zz.y) << 32 | zz.x) + exy);
+				q1 = (const uint8_t *) vol + ((((uint64_t) zz.w) << 32 | zz.z) + exy);
 			}
 		}
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
@@ -278,35 +290,37 @@ __device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
 
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
-constexpr uint32_t kThreads = 512;      // 8 waves = 32x16 pixels: one copy of the LDS tables serves twice the rays, and
-                                        // 4 workgroups per CU reach the 32-wave limit inside the 160 KiB of LDS
-
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)>::threads)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
-	constexpr bool kUseLut = LAYOUT == kLayoutBricked && ADDR != kAddrWide;
+	typedef LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)> L;
+	constexpr bool kUseLut = L::max_dim != 0;
+	constexpr uint32_t kThreads = L::threads;
 	__shared__ LdsTables lds;
-	__shared__ __attribute__((aligned(16))) uint32_t lut[kUseLut ? kLutWords : 4];
-#ifdef VR_LDS_PAD          // tuning aid: occupy extra LDS to lower the number of resident workgroups per CU
-	__shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
-	if (a.dim_x == 0xffffffffu) lds_pad[threadIdx.x] = 1;
-#endif
+	__shared__ __attribute__((aligned(16))) uint32_t lut[L::words];
 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
 		const uint32_t t = threadIdx.x;
 		if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
-			const uint32_t scale = ADDR == kAddr32 ? 4u * BPV : 1u;        // byte offsets or element indices
-			const uint32_t row = a.nbx * kBrickPitch, slab = a.nby * row;
+			const uint32_t elem = 4u * BPV;                                  // bytes per quad element
+			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
+			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t i = t; i < nz; i += kThreads) {
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
-				lut[2 * i]     = ((i >> 3) * slab + (dilate3(i & 7u) << kSlotZ)) * scale;
-				lut[2 * i + 1] = ((j >> 3) * slab + (dilate3(j & 7u) << kSlotZ)) * scale;
+				const uint64_t z0 = ((i >> 3) * slab + (dilate3(i & 7u) << kSlotZ)) * elem;
+				const uint64_t z1 = ((j >> 3) * slab + (dilate3(j & 7u) << kSlotZ)) * elem;
+				if (ADDR == kAddr32) {
+					lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) z1;
+				} else {
+					lut[4 * i] = (uint32_t) z0; lut[4 * i + 1] = (uint32_t) (z0 >> 32);
+					lut[4 * i + 2] = (uint32_t) z1; lut[4 * i + 3] = (uint32_t) (z1 >> 32);
+				}
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[kLutX + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << kSlotX)) * scale;
-			for (uint32_t i = t; i < ny; i += kThreads) lut[kLutY + i] = ((i >> 3) * row + (dilate3(i & 7u) << kSlotY)) * scale;
+			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << kSlotX)) * elem;
+			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + (dilate3(i & 7u) << kSlotY)) * elem;
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -317,7 +331,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			f4 d; d.x = c1.x - c0.x; d.y = c1.y - c0.y; d.z = c1.z - c0.z; d.w = c1.w - c0.w;
 			lds.dtf[t] = d;
 		}
-		((uint2 *) lds.esl)[t] = ((const uint2 *) esl_g)[t];       // 512 threads x 8 B = 4 KiB
+		for (uint32_t i = t; i < VR_ESL_VOLUME_SIZE; i += kThreads) lds.esl[i] = esl_g[i];
 	}
 	__syncthreads();
 
@@ -330,7 +344,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t tile = xcd * q + (xcd < r ? xcd : r) + slot;   // bijective for every ntiles
 	const uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
 
-	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16.  Inside the wave each group of 16 consecutive lanes is a
+	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16 pixels, 16 waves = 32x32.  Inside the wave each group of 16 consecutive lanes is a
 	//    4x4-pixel block (not two 8-pixel rows): the vector L1 coalesces per 16-lane group, and a compact block keeps the
 	//    group's samples inside the fewest 32-byte sectors whatever the view direction.
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -350,7 +364,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t wx = (qd & 1u) * 4u + ((lane >> 2) & 1u) * 2u + (lane & 1u), wy = (qd >> 1) * 4u + ((lane >> 3) & 1u) * 2u + ((lane >> 1) & 1u);
 #endif
 	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + wx;
-	const uint32_t ly = tile_y * 16u + (wave >> 2) * 8u + wy;
+	const uint32_t ly = tile_y * (kThreads / 32u) + (wave >> 2) * 8u + wy;
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
@@ -519,10 +533,13 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 }
 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
-static hipError_t launch_variant(const RayKernelArgs &a, const void *volume, const float *tf, const uint32_t *esl,
+static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, const float *tf, const uint32_t *esl,
                                  void *out, hipStream_t stream) {
-	const uint32_t ntiles = a.tiles_x * a.tiles_y;
-	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(ntiles), dim3(kThreads), 0, stream,
+	constexpr uint32_t threads = LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)>::threads;
+	RayKernelArgs a = args;
+	a.tiles_x = (a.p.out_width + 31u) / 32u;
+	a.tiles_y = (a.p.out_rows + threads / 32u - 1u) / (threads / 32u);
+	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), 0, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
 }
@@ -531,17 +548,17 @@ template <int BPV>
 static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
                              const uint32_t *esl, void *out, hipStream_t stream) {
 	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
-	if (bricked != nullptr && !(nearest && a.force_wide)) {
-		const uint64_t elems = bricked_elems(a.dim_x, a.dim_y, a.dim_z);
-		const bool lut_ok = !a.force_wide && a.dim_x <= kLutMaxDim && a.dim_y <= kLutMaxDim && a.dim_z <= kLutMaxDim;
-		if (lut_ok && elems * 4 * BPV <= (1ull << 32))
+	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
+	if (bricked != nullptr) {
+		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
+		if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
 			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream)
 			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
-		if (!nearest) {
-			if (lut_ok && elems < (1ull << 32))
-				return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrElem, kLayoutBricked>(a, bricked, tf, esl, out, stream);
-			return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);   // e.g. 2048^3
-		}
+		if (a.force_wide != 1 && max_dim <= LutCfg<kAddrLut64>::max_dim)
+			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream)
+			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+		if (!nearest)
+			return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);
 	}
 	// the reference's linear array; 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12)
 	const bool wide = a.force_wide || ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);

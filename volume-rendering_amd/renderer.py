@@ -71,8 +71,8 @@ class HipRenderer:
         self._check(self._L.vr_hip_set_layout(self._ctx, int(layout)), "set_layout")
 
     def set_wide_addressing(self, force):
-        """Testing aid: take the 64-bit index path (volumes > 1024^3) regardless of the volume size."""
-        self._check(self._L.vr_hip_set_wide_addressing(self._ctx, int(bool(force))), "set_wide_addressing")
+        """Testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path (what volumes > 1024^3 use), 0/False = automatic."""
+        self._check(self._L.vr_hip_set_wide_addressing(self._ctx, int(force)), "set_wide_addressing")
 
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
