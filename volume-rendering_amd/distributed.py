@@ -70,8 +70,11 @@ class FrameSplit:
 
 
 def default_band_rows(height, world):
-    """16-row bands (one workgroup tile row) interleaved over the ranks balance long centre rays against short edge
-    rays; one rank gets the whole frame."""
+    """Interleaved bands balance long centre rays against short edge rays.  128-row bands (8 workgroup tile rows — the
+    kernel walks its tiles in 8x8-tile blocks for cache locality) when every rank still gets at least two of them, one
+    from each half of the frame; otherwise 16-row bands (one tile row).  One rank gets the whole frame."""
     if world <= 1:
         return max(1, height)
+    if height % 128 == 0 and height // 128 >= 2 * world:
+        return 128
     return 16
