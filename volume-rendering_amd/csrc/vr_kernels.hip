@@ -213,6 +213,14 @@ __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f) {
 	return lerp(c0, c1, f.az);
 }
 
+// x where the wave mask has the lane's bit set, 0 elsewhere: one v_cndmask with the mask taken straight from SGPRs
+__device__ __forceinline__ float select_lanes(uint64_t mask, float x) {
+	float r;
+	asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+	return r;
+}
+enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5 };       // LLVM fcmp predicate codes for __builtin_amdgcn_fcmpf
+
 // 1/sqrt(x) of the light vector in TRILINEAR mode: integer seed + three Newton steps in plain IEEE fp32 operations,
 // identical on CPU and GPU (oracle/vr_oracle.c rsqrt_nr); relative error < 2e-7.
 __device__ __forceinline__ float rsqrt_nr(float x) {
@@ -498,6 +506,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		auto issue = [&](float k) {
 			return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z));
 		};
+		// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
+		// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
+		// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
+		uint64_t live = __builtin_amdgcn_ballot_w64(alive);
 		auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
 			const float kn = kx + step;
 			nxt = issue(kn);
@@ -511,7 +523,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			// default TF is zero below 10 % density), so a sample with tb < tf_zero_below has colour (0,0,0,0), is never
 			// shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.  If that holds for every live lane the wave
 			// skips the LDS lookups, the shading test and the composite.
-			if (__builtin_amdgcn_ballot_w64(alive && !(tb < a.tf_zero_below)) != 0ull) {
+			if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
 				f4 c;
 				{
 					const uint32_t i = (uint32_t) (int) tb;
@@ -520,26 +532,27 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
 					c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
 				}
-				if (alive && c.w > 0.05f && lit) {                                                 // GPURenderer4.cu:41-51 shade_texture
+				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
+				if (shaded != 0ull) {                                                              // GPURenderer4.cu:41-51 shade_texture
 					const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
 					const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
 					const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
 					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
 					const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
 					                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
-					const float diffuse = (raw_l - raw) * a.kd_scaled;
+					const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 					c.x += diffuse; c.y += diffuse; c.z += diffuse;
 				}
-				const float t = alive ? 1 - acc.w : 0.0f;
+				const float t = select_lanes(live, 1 - acc.w);                                     // finished lanes: weight 0
 				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
 				acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
-				alive = alive && !(acc.w > threshold);                  // ERT (CPURenderer.cpp:35-36)
+				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                        // ERT (CPURenderer.cpp:35-36)
 			}
-			alive = alive && (kn <= ky);                                // the loop condition
+			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
 			kx = kn;
 		};
 		TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
-		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+		while (live != 0ull) {
 			step_sample(fa, fb);
 			step_sample(fb, fa);
 			step_sample(fa, fb);                 // four samples per exit vote (-2.5 % against two)
