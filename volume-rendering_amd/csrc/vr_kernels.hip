@@ -219,7 +219,7 @@ __device__ __forceinline__ float select_lanes(uint64_t mask, float x) {
 	asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
 	return r;
 }
-enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5 };       // LLVM fcmp predicate codes for __builtin_amdgcn_fcmpf
+enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5, kIcmpSGT = 38 };   // LLVM fcmp / icmp predicate codes for __builtin_amdgcn_fcmpf / sicmp
 
 // 1/sqrt(x) of the light vector in TRILINEAR mode: integer seed + three Newton steps in plain IEEE fp32 operations,
 // identical on CPU and GPU (oracle/vr_oracle.c rsqrt_nr); relative error < 2e-7.
@@ -459,6 +459,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// per-wave transparent-sample shortcut, two samples per exit vote); the arithmetic is the reference's, unfused:
 		// acc + cur * 0 == acc exactly, and map_float_int clamps every index, so speculative fetches stay in bounds.
 		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
+		uint64_t live = __builtin_amdgcn_ballot_w64(alive);            // liveness as one scalar wave mask (see TRILINEAR)
 		auto step_sample = [&](const uint32_t &cur_s, uint32_t &nxt_s) {
 			const float kn = kx + step;
 			const f3 pn = march_point<SAMPLING>(origin, dir, kn);
@@ -466,29 +467,32 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			__builtin_amdgcn_sched_barrier(0);
 			const uint32_t s = cur_s;
 			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
-			if (__builtin_amdgcn_ballot_w64(alive && (int) idx > tf_zero_idx) != 0ull) {
+			if ((__builtin_amdgcn_sicmp((int) idx, tf_zero_idx, kIcmpSGT) & live) != 0ull) {
 				f4 cur = lds.tf[idx];
-				if (alive && cur.w > 0.05f && lit) {                                              // RaycasterBase.h:87-98 shade
+				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
+				if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
 					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
 					float sl = (float) sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps) / raw;
-					float diffuse = (sl - (float) s / raw) * kd;
+					const float diffuse = select_lanes(shaded, (sl - (float) s / raw) * kd);     // x + 0 == x: unshaded lanes unchanged
 					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				}
-				const float t = alive ? 1 - acc.w : 0.0f;                                         // CPURenderer.cpp:34
+				const float t = select_lanes(live, 1 - acc.w);                                    // CPURenderer.cpp:34
 				acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
 				acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
-				alive = alive && !(acc.w > threshold);                                            // CPURenderer.cpp:35-36
+				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                      // CPURenderer.cpp:35-36
 			}
-			alive = alive && (kn <= ky);
+			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
 			kx = kn;
 			pt = pn;
 		};
 		uint32_t sa = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pt), sb = 0;
-		while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+		while (live != 0ull) {
+			step_sample(sa, sb);
+			step_sample(sb, sa);
 			step_sample(sa, sb);
 			step_sample(sb, sa);
 		}
