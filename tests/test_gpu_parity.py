@@ -178,6 +178,25 @@ def test_device_buffer_path_with_torch_stream(vr, gpu, golden):
     assert t.launches >= 1 and t.kernel_ms > 0
 
 
+def test_set_volume_from_device_memory(vr, gpu, golden):
+    """vr_hip_set_volume_device: the voxels come from a buffer that is already in HBM (a torch tensor here)."""
+    import torch
+    st = load_volume(gpu, golden, "blob_40x24x56")
+    gpu.set_window_buffer(256, 256)
+    case = [c for c in golden.cases(True) if c["volume"] == "blob_40x24x56"][0]
+    vox = golden.voxels("blob_40x24x56")
+    dev = torch.from_numpy(vox.copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    for mode in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+        p = golden.params(case, mode)
+        host_path = gpu.render_volume(p)
+        gpu.set_volume_device(dev.data_ptr(), (vox.shape[2], vox.shape[1], vox.shape[0]), 1)
+        assert np.array_equal(gpu.render_volume(p), host_path)
+        assert np.array_equal(gpu.download_volume(), vox)
+        gpu.set_volume(vox)
+    assert np.array_equal(gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), golden.frame(case))
+
+
 def test_cpp_renderer_mirror(vr, gpu, golden):
     """The host C++ mirror: RaycasterBase::reset_transfer_fn/set_volume -> HipRenderer(raycaster).render_volume()."""
     vox = golden.voxels("bucky")

@@ -270,7 +270,9 @@ int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y,
 	VR_TRY(c, hipSetDevice(c->device));
 	int rc = alloc_volume(c, x, y, z, bpv);
 	if (rc) return rc;
-	VR_TRY(c, hipMemcpy(c->vol, dev, c->vol_elems * bpv, hipMemcpyDeviceToDevice));
+	// on the context's own (non-blocking) stream: a device-to-device hipMemcpy on the null stream may return before it has
+	// finished and would not be ordered before the brick builder below
+	VR_TRY(c, hipMemcpyAsync(c->vol, dev, c->vol_elems * bpv, hipMemcpyDeviceToDevice, c->stream));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
 	return finalize_volume(c);
 }
