@@ -660,18 +660,35 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint
 // One workgroup per (y-block, z-block) pair: it streams block_dims^2 rows of dim_x voxels with 16-byte loads and keeps
 // the 32 x-block minima/maxima in LDS.  min/max are order independent, so the result equals the serial scan exactly.
 
-__device__ __forceinline__ void minmax16(uint4 v, uint32_t &mn, uint32_t &mx) {
-	const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-	#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		#pragma unroll
-		for (int b = 0; b < 4; b++) {
-			uint32_t s = (w[i] >> (8 * b)) & 0xffu;
-			mn = s < mn ? s : mn; mx = s > mx ? s : mx;
-		}
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// running min / max of the 8-bit samples of one dword, two at a time in packed 16-bit lanes (v_pk_min_u16 / v_pk_max_u16)
+template <int BPV>
+__device__ __forceinline__ void minmax_word(uint32_t w, us2 &mn, us2 &mx) {
+	if (BPV == 1) {
+		const uint32_t even = w & 0x00ff00ffu, odd = (w >> 8) & 0x00ff00ffu;
+		const us2 e = __builtin_bit_cast(us2, even), o = __builtin_bit_cast(us2, odd);
+		mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(e, o));
+		mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(e, o));
+	} else {                                             // u16 volumes: the ESL grid works on the high byte
+		const us2 h = __builtin_bit_cast(us2, (w >> 8) & 0x00ff00ffu);
+		mn = __builtin_elementwise_min(mn, h);
+		mx = __builtin_elementwise_max(mx, h);
 	}
 }
 
+template <int BPV>
+__device__ __forceinline__ void minmax_chunk(uint4 v, us2 &mn, us2 &mx) {
+	minmax_word<BPV>(v.x, mn, mx); minmax_word<BPV>(v.y, mn, mx); minmax_word<BPV>(v.z, mn, mx); minmax_word<BPV>(v.w, mn, mx);
+}
+
+// One workgroup per (y-block, z-block) pair of the 32^3 ESL grid: it streams block_dims^2 rows of dim_x voxels and keeps the
+// 32 x-block minima / maxima in LDS.  Three paths, same result (min / max are order independent):
+//   streaming: a row is 1..256 16-byte chunks (a power of two) and every chunk lies inside one x-block — each thread owns
+//              one chunk COLUMN, walks the rows with 8 independent 16-byte loads in flight, reduces in registers and touches
+//              LDS once at the end.  This is the HBM-bound path (1024^3: 64 chunks per row, 4 rows per pass);
+//   chunked  : 16-byte chunks inside one x-block, any row length;
+//   generic  : one voxel at a time (odd dimensions, block edges that are not a multiple of the chunk).
 template <int BPV>
 __global__ __launch_bounds__(256)
 void minmax_kernel(const void *__restrict__ vol, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t bd,
@@ -685,30 +702,39 @@ void minmax_kernel(const void *__restrict__ vol, uint32_t dim_x, uint32_t dim_y,
 	const uint32_t rows = ny * nz;
 	const uint64_t row_bytes = (uint64_t) dim_x * BPV;
 	const uint32_t chunk_voxels = 16 / BPV;
-	// fast path: every 16-byte chunk lies inside one x-block and rows are 16-byte aligned
-	const bool fast = (dim_x % chunk_voxels == 0) && (bd % chunk_voxels == 0);
-	if (fast) {
-		const uint32_t chunks_per_row = dim_x / chunk_voxels;
-		const uint64_t total = (uint64_t) rows * chunks_per_row;
-		for (uint64_t c = threadIdx.x; c < total; c += 256) {
-			const uint32_t row = (uint32_t) (c / chunks_per_row), cx = (uint32_t) (c - (uint64_t) row * chunks_per_row);
+	const bool chunked = (dim_x % chunk_voxels == 0) && (bd % chunk_voxels == 0);
+	const uint32_t cpr = chunked ? dim_x / chunk_voxels : 0;          // chunks per row
+	if (chunked && cpr <= 256 && (cpr & (cpr - 1)) == 0) {
+		const uint32_t rows_per_pass = 256 / cpr;
+		const uint32_t cx = threadIdx.x & (cpr - 1), r0 = threadIdx.x / cpr;
+		us2 mn = { 255, 255 }, mx = { 0, 0 };
+		auto row_ptr = [&](uint32_t row) {
+			const uint32_t z = z0 + row / ny, y = y0 + row - (row / ny) * ny;
+			return (const uint4 *) ((const uint8_t *) vol + ((uint64_t) z * dim_y + y) * row_bytes + (uint64_t) cx * 16);
+		};
+		uint32_t row = r0;
+		for (; row + 7 * rows_per_pass < rows; row += 8 * rows_per_pass) {
+			uint4 v[8];
+			#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = *row_ptr(row + u * rows_per_pass);
+			#pragma unroll
+			for (int u = 0; u < 8; u++) minmax_chunk<BPV>(v[u], mn, mx);
+		}
+		for (; row < rows; row += rows_per_pass) minmax_chunk<BPV>(*row_ptr(row), mn, mx);
+		const uint32_t xb = (cx * chunk_voxels) / bd;
+		atomicMin(&smin[xb], (uint32_t) min(mn.x, mn.y));
+		atomicMax(&smax[xb], (uint32_t) max(mx.x, mx.y));
+	} else if (chunked) {
+		const uint32_t total = rows * cpr;                            // < 2^32: rows <= 2^16 * 2^16 / ... bounded by the slab size
+		for (uint32_t c = threadIdx.x; c < total; c += 256) {
+			const uint32_t row = c / cpr, cx = c - row * cpr;
 			const uint32_t y = y0 + row % ny, z = z0 + row / ny;
 			const uint8_t *p = (const uint8_t *) vol + ((uint64_t) z * dim_y + y) * row_bytes + (uint64_t) cx * 16;
-			const uint4 v = *(const uint4 *) p;
-			uint32_t mn = 255u, mx = 0u;
-			if (BPV == 1) {
-				minmax16(v, mn, mx);
-			} else {                                     // u16: ESL works on the high byte
-				const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-				#pragma unroll
-				for (int i = 0; i < 4; i++) {
-					uint32_t s0 = (w[i] >> 8) & 0xffu, s1 = w[i] >> 24;
-					mn = min(mn, min(s0, s1)); mx = max(mx, max(s0, s1));
-				}
-			}
+			us2 mn = { 255, 255 }, mx = { 0, 0 };
+			minmax_chunk<BPV>(*(const uint4 *) p, mn, mx);
 			const uint32_t xb = (cx * chunk_voxels) / bd;
-			atomicMin(&smin[xb], mn);
-			atomicMax(&smax[xb], mx);
+			atomicMin(&smin[xb], (uint32_t) min(mn.x, mn.y));
+			atomicMax(&smax[xb], (uint32_t) max(mx.x, mx.y));
 		}
 	} else {
 		const uint64_t total = (uint64_t) rows * dim_x;
