@@ -343,23 +343,40 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	}
 	__syncthreads();
 
-	// -- XCD-aware workgroup -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2):
-	//    give XCD x the x-th contiguous chunk of the row-major tile list, so tiles that share voxel rows share an L2.
+	// -- workgroup -> tile map, chosen by measurement on the 8-XCD chip (scripts/gpu_variants.sh, lit full march, 8-view
+	//    mean).  Tiles are numbered in BxB-tile blocks (B = 8: 256x128 pixels), so the ~1000 workgroups in flight at any time
+	//    cover a compact screen region and share bricks in both screen directions (row-major numbering: +3..7 %).  Workgroups
+	//    are dealt round-robin over the XCDs (b and b + 8 share an L2); three assignments of tiles to XCDs were measured:
+	//      0  tile = workgroup id — every block is spread over all eight XCDs (XCD x renders column x of each block)   4.66 ms
+	//      1  each XCD owns one contiguous eighth of the tile list (one screen band per L2)                            6.25 ms
+	//      2  each XCD owns whole blocks, interleaved over the frame                                                   6.06 ms
+	//    Concentrating a compact brick region on ONE L2 (1, 2) is markedly slower than letting all eight L2s serve it —
+	//    the reuse between neighbouring tiles is small (the quad elements already carry the +1 neighbours) and a compact
+	//    region exercises few L2 channels — so the plain interleave (0) is the default.  Placement affects speed only.
+#ifndef VR_TILE_ORDER
+#define VR_TILE_ORDER 8
+#endif
+#ifndef VR_XCD_MODE
+#define VR_XCD_MODE 0
+#endif
+	constexpr uint32_t B = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
 	const uint32_t ntiles = a.tiles_x * a.tiles_y;
 	const uint32_t bid = blockIdx.x;
-	const uint32_t xcd = bid & 7u, slot = bid >> 3;
-	const uint32_t q = ntiles >> 3, r = ntiles & 7u;
-	const uint32_t tile = xcd * q + (xcd < r ? xcd : r) + slot;   // bijective for every ntiles
-#ifndef VR_TILE_ORDER
-#define VR_TILE_ORDER 8          // measured: row-major 6.85 ms, 4 -> 6.53, 8 -> 6.38, 16 -> 6.60 (lit full march, 8-view mean)
-#endif
+	const uint32_t full_cols = a.tiles_x / B, full_rows = a.tiles_y / B;
+	const uint32_t nblocked = full_cols * full_rows * B * B;          // tiles that lie in complete BxB blocks
+	uint32_t tile = bid;
+	if (VR_XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
+		const uint32_t xcd = bid & 7u, slot = bid >> 3, q = ntiles >> 3, r = ntiles & 7u;
+		tile = xcd * q + (xcd < r ? xcd : r) + slot;
+	} else if (VR_XCD_MODE == 2) {                                    // whole blocks per XCD, interleaved over the frame
+		const uint32_t covered = (nblocked / (8u * B * B)) * (8u * B * B);
+		if (bid < covered) {
+			const uint32_t set = bid / (8u * B * B), within = bid - set * (8u * B * B);
+			tile = (set * 8u + (within & 7u)) * (B * B) + (within >> 3);
+		}
+	}
 	uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
-	if (VR_TILE_ORDER > 1) {
-		// blocked order: consecutive tiles fill BxB-tile squares, so the workgroups resident on an XCD at one time cover a
-		// compact screen region (their rays share bricks in both screen directions) instead of a thin band
-		constexpr uint32_t B = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 2;
-		const uint32_t full_cols = a.tiles_x / B, full_rows = a.tiles_y / B;
-		const uint32_t nblocked = full_cols * full_rows * B * B;
+	if (B > 1) {
 		if (tile < nblocked) {
 			const uint32_t blk = tile / (B * B), in = tile - blk * (B * B);
 			const uint32_t by = blk / full_cols, bx = blk - by * full_cols;
