@@ -307,6 +307,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	constexpr uint32_t kThreads = L::threads;
 	__shared__ LdsTables lds;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[L::words];
+#ifdef VR_LDS_PAD          // tuning aid: occupy extra LDS to lower the number of resident workgroups per CU
+	__shared__ uint32_t lds_pad[VR_LDS_PAD / 4];
+	if (a.dim_x == 0xffffffffu) lds_pad[threadIdx.x] = 1;
+#endif
 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
