@@ -793,39 +793,46 @@ hipError_t launch_minmax(const void *volume, uint32_t bpv, uint32_t dim_x, uint3
 
 // ---- feeders: 256-bin histogram (ModelBase.cpp:19-26) ----------------------------------------------------------------------
 
+// Each wave keeps kHistCopies interleaved copies of the 256 bins in LDS (bin b of copy c at b * kHistCopies + c, c = lane % 8):
+// real volumes are dominated by a few values (air), and lanes that hit the same bin in one ds_add serialise — spreading them
+// over 8 copies in 8 different banks cuts that 8-fold.  16-byte loads, 4 in flight per thread.
+constexpr uint32_t kHistCopies = 8;
+
 template <int BPV>
 __global__ __launch_bounds__(256)
 void histogram_kernel(const void *__restrict__ vol, uint64_t voxels, unsigned long long *__restrict__ hist) {
-	__shared__ uint32_t sh[4][256];                      // one sub-histogram per wave: fewer same-address LDS atomics
-	for (uint32_t i = threadIdx.x; i < 1024; i += 256) ((uint32_t *) sh)[i] = 0;
+	__shared__ uint32_t sh[4][256 * kHistCopies];
+	for (uint32_t i = threadIdx.x; i < 4 * 256 * kHistCopies; i += 256) ((uint32_t *) sh)[i] = 0;
 	__syncthreads();
-	uint32_t *mine = sh[threadIdx.x >> 6];
-	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	const uint64_t vec = voxels * BPV / 16;              // whole 16-byte chunks
-	for (uint64_t c = (uint64_t) blockIdx.x * 256 + threadIdx.x; c < vec; c += stride) {
-		const uint4 v = ((const uint4 *) vol)[c];
+	uint32_t *mine = sh[threadIdx.x >> 6] + (threadIdx.x & (kHistCopies - 1));
+	auto count = [&](uint32_t bin) { atomicAdd(&mine[bin * kHistCopies], 1u); };
+	auto chunk = [&](uint4 v) {
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 		#pragma unroll
 		for (int i = 0; i < 4; i++) {
-			if (BPV == 1) {
-				atomicAdd(&mine[w[i] & 0xffu], 1u); atomicAdd(&mine[(w[i] >> 8) & 0xffu], 1u);
-				atomicAdd(&mine[(w[i] >> 16) & 0xffu], 1u); atomicAdd(&mine[w[i] >> 24], 1u);
-			} else {
-				atomicAdd(&mine[(w[i] >> 8) & 0xffu], 1u); atomicAdd(&mine[w[i] >> 24], 1u);
-			}
+			if (BPV == 1) { count(w[i] & 0xffu); count((w[i] >> 8) & 0xffu); count((w[i] >> 16) & 0xffu); count(w[i] >> 24); }
+			else          { count((w[i] >> 8) & 0xffu); count(w[i] >> 24); }          // u16: high byte
 		}
+	};
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	const uint64_t vec = voxels * BPV / 16;              // whole 16-byte chunks
+	uint64_t c = (uint64_t) blockIdx.x * 256 + threadIdx.x;
+	for (; c + 3 * stride < vec; c += 4 * stride) {
+		const uint4 v0 = ((const uint4 *) vol)[c], v1 = ((const uint4 *) vol)[c + stride];
+		const uint4 v2 = ((const uint4 *) vol)[c + 2 * stride], v3 = ((const uint4 *) vol)[c + 3 * stride];
+		chunk(v0); chunk(v1); chunk(v2); chunk(v3);
 	}
-	// tail (fewer than 16 bytes)
-	if (blockIdx.x == 0) {
+	for (; c < vec; c += stride) chunk(((const uint4 *) vol)[c]);
+	if (blockIdx.x == 0) {                               // tail (fewer than 16 bytes)
 		const uint64_t done = vec * 16 / BPV;
-		for (uint64_t i = done + threadIdx.x; i < voxels; i += 256) {
-			const uint32_t s = BPV == 1 ? ((const uint8_t *) vol)[i] : (uint32_t) (((const uint16_t *) vol)[i] >> 8);
-			atomicAdd(&mine[s], 1u);
-		}
+		for (uint64_t i = done + threadIdx.x; i < voxels; i += 256)
+			count(BPV == 1 ? ((const uint8_t *) vol)[i] : (uint32_t) (((const uint16_t *) vol)[i] >> 8));
 	}
 	__syncthreads();
 	const uint32_t b = threadIdx.x;
-	const unsigned long long sum = (unsigned long long) sh[0][b] + sh[1][b] + sh[2][b] + sh[3][b];
+	unsigned long long sum = 0;
+	for (uint32_t w = 0; w < 4; w++)
+		for (uint32_t cp = 0; cp < kHistCopies; cp++) sum += sh[w][b * kHistCopies + cp];
 	if (sum) atomicAdd(&hist[b], sum);
 }
 
