@@ -27,6 +27,9 @@ struct RayKernelArgs {
 	float    tf_scale;                 // 128/255 (u8) or 128/65535 (u16): raw interpolated voxel -> TF texel coordinate + 0.5
 	float    kd_scaled;                // light_kd / 255 (u8) or / 65535 (u16)
 	float    tf_zero_below;            // entries 0..tf_zero_below of the premultiplied TF are exactly (0,0,0,0); -1 if entry 0 is not
+	uint32_t skip_mask;                // per-voxel bit mask ~(skip_below - 1), replicated over the packed word: all 8 corners below the
+	                                   // power of two skip_below => TF coordinate <= tf_zero_below
+	uint32_t skip_never;               // 1 when the TF has no leading zero entries (the corner test must always fail), else 0
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes

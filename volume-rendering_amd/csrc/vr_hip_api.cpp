@@ -117,6 +117,16 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.tf_scale = c->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
 	a.kd_scaled = p->light_kd * (c->bpv == 1 ? (1.0f / 255.0f) : (1.0f / 65535.0f));
 	a.tf_zero_below = c->tf_zero_below;
+	{   // largest power of two P with fma(P, tf_scale, -0.5) <= tf_zero_below: raw < P implies a transparent sample
+		uint32_t below = 0;
+		const uint32_t top = c->bpv == 1 ? 256u : 65536u;
+		for (uint32_t P = 1; P <= top; P <<= 1)
+			if (c->tf_zero_below >= 0.0f && std::fmaf((float) P, a.tf_scale, -0.5f) <= c->tf_zero_below) below = P;
+		a.skip_never = below == 0 ? 1u : 0u;
+		if (below == 0) a.skip_mask = 0xffffffffu;
+		else if (c->bpv == 1) a.skip_mask = ((0xffu & ~(below - 1u)) * 0x01010101u);
+		else a.skip_mask = ((0xffffu & ~(below - 1u)) * 0x00010001u);
+	}
 	a.force_wide = c->force_wide;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;

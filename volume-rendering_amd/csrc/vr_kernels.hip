@@ -219,7 +219,7 @@ __device__ __forceinline__ float select_lanes(uint64_t mask, float x) {
 	asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
 	return r;
 }
-enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5, kIcmpSGT = 38 };   // LLVM fcmp / icmp predicate codes for __builtin_amdgcn_fcmpf / sicmp
+enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5, kIcmpNE = 33, kIcmpSGT = 38 };   // LLVM fcmp / icmp predicate codes for __builtin_amdgcn_fcmpf / sicmp
 
 // 1/sqrt(x) of the light vector in TRILINEAR mode: integer seed + three Newton steps in plain IEEE fp32 operations,
 // identical on CPU and GPU (oracle/vr_oracle.c rsqrt_nr); relative error < 2e-7.
@@ -541,13 +541,21 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #ifndef VR_NO_SCHED_BARRIER
 			__builtin_amdgcn_sched_barrier(0);
 #endif
+			// Exact shortcuts, decided per wave.  Entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
+			// default TF is zero below 10 % density), so a sample whose TF coordinate tb is <= tf_zero_below has colour
+			// (0,0,0,0), is never shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.
+			//  (1) before any arithmetic: if all 8 corner voxels of every live lane are below the power of two `skip_below`
+			//      (a bit test on the packed words), the interpolated value is too — a lerp never leaves [min, max] of its
+			//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
+			//      follows: the wave skips unpacking, the 7 lerps and everything after them;
+			//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
+			uint32_t corners;
+			if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
+			else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
+			if ((__builtin_amdgcn_uicmp((corners & a.skip_mask) | a.skip_never, 0u, kIcmpNE) & live) != 0ull) {
 			const float raw = tri_resolve<BPV, LAYOUT>(cur);                                       // GPURenderer4.cu:76
 			// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
 			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-			// Exact shortcut, decided per wave: entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
-			// default TF is zero below 10 % density), so a sample with tb < tf_zero_below has colour (0,0,0,0), is never
-			// shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.  If that holds for every live lane the wave
-			// skips the LDS lookups, the shading test and the composite.
 			if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
 				f4 c;
 				{
@@ -572,6 +580,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
 				acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
 				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                        // ERT (CPURenderer.cpp:35-36)
+			}
 			}
 			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
 			kx = kn;
