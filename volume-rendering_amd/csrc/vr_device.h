@@ -51,29 +51,23 @@ struct RayKernelArgs {
 enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
-// 3-bit Morton dilation: bit i of v moves to bit 3*i
-__host__ __device__ inline uint32_t dilate3(uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); }
-__host__ __device__ inline uint32_t undilate3(uint32_t v) { return (v & 1u) | ((v >> 2) & 2u) | ((v >> 4) & 4u); }
-// which interleave slot (bit 0, 1 or 2 of every 3-bit group) each axis occupies inside a brick
-#ifndef VR_MORTON_PERM
-#define VR_MORTON_PERM 5
+// Where each coordinate bit lands inside the 9-bit element offset of a brick: positions of x0 x1 x2, y0 y1 y2, z0 z1 z2.
+// Default = Z-order (Morton) with z in the lowest, y in the middle and x in the top slot of every 3-bit group (measured best
+// of the six slot assignments).  -DVR_BRICK_BITS=... selects another placement (measurement aid).
+#ifndef VR_BRICK_BITS
+#define VR_BRICK_BITS 2, 5, 8, 1, 4, 7, 0, 3, 6
 #endif
-#if VR_MORTON_PERM == 0
-constexpr uint32_t kSlotX = 1, kSlotY = 2, kSlotZ = 0;
-#elif VR_MORTON_PERM == 1
-constexpr uint32_t kSlotX = 0, kSlotY = 1, kSlotZ = 2;
-#elif VR_MORTON_PERM == 2
-constexpr uint32_t kSlotX = 2, kSlotY = 0, kSlotZ = 1;
-#elif VR_MORTON_PERM == 3
-constexpr uint32_t kSlotX = 0, kSlotY = 2, kSlotZ = 1;
-#elif VR_MORTON_PERM == 4
-constexpr uint32_t kSlotX = 1, kSlotY = 0, kSlotZ = 2;
-#elif VR_MORTON_PERM == 5
-constexpr uint32_t kSlotX = 2, kSlotY = 1, kSlotZ = 0;
-#endif
+constexpr uint32_t kBrickBits[9] = { VR_BRICK_BITS };
+// AXIS 0 = x, 1 = y, 2 = z: spread the three low bits of a coordinate to their positions / collect them again
+template <int AXIS> __host__ __device__ inline uint32_t brick_spread(uint32_t v) {
+	return ((v & 1u) << kBrickBits[3 * AXIS]) | (((v >> 1) & 1u) << kBrickBits[3 * AXIS + 1]) | (((v >> 2) & 1u) << kBrickBits[3 * AXIS + 2]);
+}
+template <int AXIS> __host__ __device__ inline uint32_t brick_collect(uint32_t local) {
+	return ((local >> kBrickBits[3 * AXIS]) & 1u) | (((local >> kBrickBits[3 * AXIS + 1]) & 1u) << 1) | (((local >> kBrickBits[3 * AXIS + 2]) & 1u) << 2);
+}
 // element offset inside a brick
 __host__ __device__ inline uint32_t brick_local(uint32_t lx, uint32_t ly, uint32_t lz) {
-	return (dilate3(lz) << kSlotZ) | (dilate3(lx) << kSlotX) | (dilate3(ly) << kSlotY);
+	return brick_spread<0>(lx) | brick_spread<1>(ly) | brick_spread<2>(lz);
 }
 
 // Volume resident in HBM: the reference's linear layout (x fastest, then y, then z — ModelBase.h:18-22) followed by

@@ -120,6 +120,9 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
 	uint32_t w0, w1, w2, w3;
 	float ax, ay, az;
+#ifdef VR_EXP_DUP_LOADS
+	uint32_t d0, d1;                                 // measurement only: the same two loads issued a second time (L1 hits)
+#endif
 };
 
 template <int BPV, int ADDR, int LAYOUT>
@@ -138,9 +141,9 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		if (ADDR == kAddrWide) {
 			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
 			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
-			const uint32_t lxy = (dilate3(ix & 7u) << kSlotX) | (dilate3(iy & 7u) << kSlotY);
-			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz & 7u) << kSlotZ))) * kElem;
-			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | (dilate3(iz1 & 7u) << kSlotZ))) * kElem;
+			const uint32_t lxy = brick_spread<0>(ix & 7u) | brick_spread<1>(iy & 7u);
+			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread<2>(iz & 7u))) * kElem;
+			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread<2>(iz1 & 7u))) * kElem;
 		} else {
 			// per-axis byte-offset tables in LDS (LutCfg): brick base + Morton-dilated in-brick offset, split by axis
 			typedef LutCfg<ADDR> L;
@@ -158,6 +161,13 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
+#ifdef VR_EXP_DUP_LOADS
+			{
+				uint64_t l0 = (uint64_t) q0, l1 = (uint64_t) q1;
+				asm volatile("" : "+v"(l0), "+v"(l1));      // opaque copies of the addresses: no CSE with the loads above
+				f.d0 = *(const uint32_t *) l0; f.d1 = *(const uint32_t *) l1;
+			}
+#endif
 		} else {                                         // 2 x global_load_dwordx2, 8-byte aligned
 			const uint2 lo = *(const uint2 *) q0, hi = *(const uint2 *) q1;
 			f.w0 = lo.x; f.w1 = lo.y; f.w2 = hi.x; f.w3 = hi.y;
@@ -322,8 +332,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t i = t; i < nz; i += kThreads) {
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
-				const uint64_t z0 = ((i >> 3) * slab + (dilate3(i & 7u) << kSlotZ)) * elem;
-				const uint64_t z1 = ((j >> 3) * slab + (dilate3(j & 7u) << kSlotZ)) * elem;
+				const uint64_t z0 = ((i >> 3) * slab + brick_spread<2>(i & 7u)) * elem;
+				const uint64_t z1 = ((j >> 3) * slab + brick_spread<2>(j & 7u)) * elem;
 				if (ADDR == kAddr32) {
 					lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) z1;
 				} else {
@@ -331,8 +341,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					lut[4 * i + 2] = (uint32_t) z1; lut[4 * i + 3] = (uint32_t) (z1 >> 32);
 				}
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + (dilate3(i & 7u) << kSlotX)) * elem;
-			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + (dilate3(i & 7u) << kSlotY)) * elem;
+			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + brick_spread<0>(i & 7u)) * elem;
+			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + brick_spread<1>(i & 7u)) * elem;
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -549,6 +559,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
 			//      follows: the wave skips unpacking, the 7 lerps and everything after them;
 			//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
+#ifdef VR_EXP_DUP_LOADS
+			if (LAYOUT == kLayoutBricked && BPV == 1) asm volatile("" :: "v"(cur.d0), "v"(cur.d1));
+#endif
 			uint32_t corners;
 			if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
 			else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
@@ -658,7 +671,7 @@ void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint3
 		const uint64_t brick = o / kBrickPitch;
 		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
 		// undo the Morton order
-		const uint32_t lz = undilate3(local >> kSlotZ), lx = undilate3(local >> kSlotX), ly = undilate3(local >> kSlotY);
+		const uint32_t lz = brick_collect<2>(local), lx = brick_collect<0>(local), ly = brick_collect<1>(local);
 		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
 		const uint32_t by = br / nbx, bx = br - by * nbx;
 		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
