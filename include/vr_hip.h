@@ -130,6 +130,12 @@ int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
  * 2048), 2 = address tables with 64-bit z offsets (dims up to 2048), 0 = automatic.  Images are identical either way. */
 int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
 
+/* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
+ * lane_map -1 = chosen per frame from the view (default); 0 = 4 pixels along screen x, 1 = along screen y, 2 = 2x2-pixel
+ * blocks; phase_x / phase_y (0..7) shift the tile grid left / down (ignored when lane_map is -1).  Testing and tuning aid
+ * (tests force every combination and compare the images).  No reference counterpart. */
+int vr_hip_set_tile_mapping(vr_ctx *ctx, int32_t lane_map, uint32_t phase_x, uint32_t phase_y);
+
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
  *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.

@@ -24,10 +24,13 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--light", type=float, default=0.6)
     ap.add_argument("--layout", default="bricked")
+    ap.add_argument("--tile-map", default="", help="lane_map,phase_x,phase_y (default: automatic)")
     a = ap.parse_args()
     vr = importlib.import_module("volume-rendering_amd")
     r = vr.HipRenderer(0)
     r.set_layout(vr.LAYOUT_BRICKED if a.layout == "bricked" else vr.LAYOUT_LINEAR)
+    if a.tile_map:
+        r.set_tile_mapping(*[int(x) for x in a.tile_map.split(",")])
     n, W = a.volume, a.viewport
     r.generate_volume(a.kind, n, seed=1)
     mm, _, _, ms = r.volume_minmax()

@@ -58,6 +58,45 @@ int main() {
 	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 32 + ((l & 7) / 2) * 4; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, rows 32 B apart (view along z)");
 	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 256 + ((l & 7) / 2) * 4; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, rows 256 B apart");
 	for (int l = 0; l < 64; l++) h[l] = ((l >> 3) / 2) * 256 + ((l & 7) / 2) * 32; run(buf, out, d_off, h, "E: 8x8 tile -> 4x4 elements, 32 B and 256 B strides");
+	// G: the ray-march kernel's own gather — 8x8-pixel tile (4x4-pixel lane groups) at `pitch` voxels per pixel on an axis
+	// plane or an oblique plane, quad elements (4 B) in Morton bricks (z lowest, y middle, x top slot), one slice
+	{
+		auto dil = [](int v) { return (v & 1) | ((v & 2) << 2) | ((v & 4) << 4); };
+		const float pitches[3] = { 0.5f, 0.865f, 1.5f };
+		for (float pitch : pitches) for (int plane = 0; plane < 4; plane++) {
+			for (int l = 0; l < 64; l++) {
+				const int qd = l >> 4, i = (qd & 1) * 4 + (l & 3), j = (qd >> 1) * 4 + ((l >> 2) & 3);
+				const float a = 0.3f + i * pitch, b = 0.6f + j * pitch;
+				float x, y, z;
+				if (plane == 0) { x = a; y = b; z = 3.2f; }
+				else if (plane == 1) { x = a; z = b; y = 3.2f; }
+				else if (plane == 2) { y = a; z = b; x = 3.2f; }
+				else { x = 0.707f * a + 0.408f * b + 2.f; y = -0.707f * a + 0.408f * b + 9.f; z = -0.816f * b + 12.f; }
+				const int ix = (int) x, iy = (int) y, iz = (int) z;
+				const int brick = (iz >> 3) * 4 + (iy >> 3) * 2 + (ix >> 3);     // 2x2x2 bricks are plenty
+				h[l] = (brick * 512 + (dil(iz & 7) | (dil(iy & 7) << 1) | (dil(ix & 7) << 2))) * 4;
+			}
+			snprintf(name, sizeof name, "G: kernel gather, pitch %.3f, plane %d", pitch, plane); run(buf, out, d_off, h, name);
+		}
+	}
+	// H: the exact lane pattern of the headline frame (ortho, 0.5 voxel per pixel: texel = 0.5 * pixel - 0.5) for a tile at
+	// pixel (16, 16) of an axis-aligned view, with two in-brick bit placements (x0 x1 x2 y0 y1 y2 z0 z1 z2 -> bit)
+	{
+		const int orders[3][9] = { { 2, 5, 8, 1, 4, 7, 0, 3, 6 }, { 0, 2, 5, 1, 3, 6, 4, 7, 8 }, { 4, 7, 8, 0, 2, 5, 1, 3, 6 } };
+		const char *oname[3] = { "morton zyx", "flat xy   ", "flat yz   " };
+		for (int phase = 16; phase <= 17; phase++) for (int o = 0; o < 3; o++) for (int plane = 0; plane < 3; plane++) {
+			auto spread = [&](int v, int axis) { return ((v & 1) << orders[o][3 * axis]) | (((v >> 1) & 1) << orders[o][3 * axis + 1]) | (((v >> 2) & 1) << orders[o][3 * axis + 2]); };
+			for (int l = 0; l < 64; l++) {
+				const int qd = l >> 4, i = (qd & 1) * 4 + (l & 3), j = (qd >> 1) * 4 + ((l >> 2) & 3);
+				const int ca = (phase + i - 1) >> 1, cb = (phase + j - 1) >> 1, cc = 3;
+				int ix, iy, iz;
+				if (plane == 0) { ix = ca; iy = cb; iz = cc; } else if (plane == 1) { ix = ca; iz = cb; iy = cc; } else { iy = ca; iz = cb; ix = cc; }
+				const int brick = (iz >> 3) * 4 + (iy >> 3) * 2 + (ix >> 3);
+				h[l] = (brick * 512 + (spread(ix & 7, 0) | spread(iy & 7, 1) | spread(iz & 7, 2))) * 4;
+			}
+			snprintf(name, sizeof name, "H: headline tile at pixel %d, %s, plane %d", phase, oname[o], plane); run(buf, out, d_off, h, name);
+		}
+	}
 	// all lanes same dword
 	for (int l = 0; l < 64; l++) h[l] = 0; run(buf, out, d_off, h, "F: all lanes one dword");
 	return 0;

@@ -139,6 +139,39 @@ def test_wide_addressing_path(vr, gpu, golden, oracle):
         gpu.set_layout(vr.LAYOUT_BRICKED)
 
 
+def test_tile_mapping_never_changes_the_image(vr, gpu, golden, oracle):
+    """Lane order inside the 4x4-pixel blocks and the tile-grid phase are scheduling only (vr_hip_set_tile_mapping): every
+    forced combination, and the automatic choice, give the oracle's image — whole frame, ragged window, and a banded partition."""
+    vox8 = golden.voxels("blob_40x24x56")
+    st = golden.volume_state("blob_40x24x56")
+    gpu.set_volume(vox8)
+    gpu.set_transfer_fn(st["tf"], st["esl"])
+    cases = [c for c in golden.cases(True) if c["volume"] == "blob_40x24x56"][:2]
+    try:
+        for case in cases:
+            for mode in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+                p = golden.params(case, mode)
+                gpu.set_window_buffer(p.view.width, p.view.height)
+                ref = oracle.render(p, vox8, st["tf"], st["esl"])
+                gpu.set_tile_mapping(-1)
+                assert np.array_equal(gpu.render_volume(p), ref), (case["label"], mode, "auto")
+                for lane_map in (0, 1, 2):
+                    for px, py in ((0, 0), (1, 0), (3, 2), (7, 7), (5, 0)):
+                        gpu.set_tile_mapping(lane_map, px, py)
+                        assert np.array_equal(gpu.render_volume(p), ref), (case["label"], mode, lane_map, px, py)
+        # banded partition (rank 1 of 3, 16-row bands) with a shifted grid
+        p = golden.params(cases[0], vr.SAMPLE_TRILINEAR)
+        whole = oracle.render(p, vox8, st["tf"], st["esl"])
+        part, _ = vr.band_partition(golden.params(cases[0], vr.SAMPLE_TRILINEAR), 1, 3, 16)
+        ref_part = oracle.render(part, vox8, st["tf"], st["esl"])
+        for lane_map, px, py in ((-1, 0, 0), (2, 3, 1), (1, 6, 5)):
+            gpu.set_tile_mapping(lane_map, px, py)
+            assert np.array_equal(gpu.render_volume(part), ref_part), (lane_map, px, py)
+        assert whole.shape[0] >= ref_part.shape[0]
+    finally:
+        gpu.set_tile_mapping(-1)
+
+
 def test_partition_concatenates_to_the_whole_frame(vr, gpu, golden):
     """SURVEY §8e correctness check: n ranks' bands assembled == 1-rank frame, byte for byte."""
     from importlib import import_module

@@ -19,6 +19,9 @@ struct RayKernelArgs {
 	vr_params p;
 	uint32_t dim_x, dim_y, dim_z;      // Model::dims (ModelBase.h:13), widened
 	uint32_t tiles_x, tiles_y;         // workgroup tiles (32x16 or 32x32 pixels) over the output; filled in at launch
+	uint32_t phase_x, phase_y;         // the tile grid starts at pixel (-phase_x, -phase_y) of the output buffer (0..7)
+	uint32_t lane_map;                 // order of the 16 lanes of a 4x4-pixel group: kLaneRows (4 consecutive lanes = 4 pixels along
+	                                   // screen x), kLaneColumns (along screen y), kLaneBlocks (2x2-pixel blocks)
 	uint64_t stride_y, stride_z;       // voxel strides (elements): dim_x, dim_x*dim_y
 	float    half_x, half_y, half_z;   // 0.5f * dim  (TRILINEAR coordinate: xb = fma(pos, half, half - 0.5))
 	float    off_x,  off_y,  off_z;    // 0.5f * dim - 0.5f
@@ -49,13 +52,16 @@ struct RayKernelArgs {
 //                   distinct 32-byte sector a 16-lane group touches (scripts/ubench/tcp_coalesce.hip), and with this
 //                   layout that count no longer depends on the view direction.  Costs 4x the voxel bytes in HBM.
 enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1 };
+enum : uint32_t { kLaneRows = 0, kLaneColumns = 1, kLaneBlocks = 2 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
 // Where each coordinate bit lands inside the 9-bit element offset of a brick: positions of x0 x1 x2, y0 y1 y2, z0 z1 z2.
-// Default = Z-order (Morton) with z in the lowest, y in the middle and x in the top slot of every 3-bit group (measured best
-// of the six slot assignments).  -DVR_BRICK_BITS=... selects another placement (measurement aid).
+// Default: x0 y0 | x1 y1 | z0 | x2 y2 | z1 z2 — every aligned 16-byte chunk (the unit the vector memory pipeline serves a
+// lane quad from) is a 2x2 (x,y) block of elements, every 64 bytes a 4x4 block, every 128-byte line a 4x4x2 block.
+// Measured against Z-order with every slot assignment (scripts/gpu_variants.sh).
+// -DVR_BRICK_BITS=... selects another placement (measurement aid).
 #ifndef VR_BRICK_BITS
-#define VR_BRICK_BITS 2, 5, 8, 1, 4, 7, 0, 3, 6
+#define VR_BRICK_BITS 0, 2, 5, 1, 3, 6, 4, 7, 8
 #endif
 constexpr uint32_t kBrickBits[9] = { VR_BRICK_BITS };
 // AXIS 0 = x, 1 = y, 2 = z: spread the three low bits of a coordinate to their positions / collect them again

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,6 +41,8 @@ struct vr_ctx {
 	void *vol_bricked = nullptr;            // TRILINEAR copy in the bricked layout (vr_device.h), built by set_volume
 	uint32_t layout = VR_LAYOUT_BRICKED;
 	uint32_t force_wide = 0;
+	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
+	uint32_t tile_phase_x = 0, tile_phase_y = 0;
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -104,6 +107,72 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 	return VR_OK;
 }
 
+// Which pixels share a lane quad, and where the tile grid starts — speed only, the image does not depend on it.
+// Measured on MI355X (scripts/ubench/tcp_coalesce.hip): the vector memory pipeline handles a wave's
+// gather 4 consecutive lanes at a time and runs ~3.5x faster when the 4 addresses share one aligned 16-byte chunk (= the
+// 2x2 (x,y) element block of the brick order).  So:
+//  * a view along a volume axis puts 2x2-pixel blocks into a quad (kLaneBlocks): at the usual >= 2 pixels per voxel the four
+//    samples fall into one or two cells;
+//  * any other view keeps 4x1-pixel quads, along the screen axis whose image in the volume stays closest to the x/y plane;
+//  * orthogonal views also shift the tile grid by 0..3 pixels so that 4-pixel groups start on even cells (when the pixel
+//    pitch is commensurate with the voxel grid — the reference's default zoom — every quad then reads a single chunk).
+void choose_tile_mapping(RayKernelArgs &a) {
+	const vr_view &v = a.p.view;
+	const float half[3] = { a.half_x, a.half_y, a.half_z }, off[3] = { a.off_x, a.off_y, a.off_z };
+	float d[3], sx[3], sy[3];
+	for (int i = 0; i < 3; i++) { d[i] = v.direction[i] * half[i]; sx[i] = v.right_plane[i] * half[i]; sy[i] = v.up_plane[i] * half[i]; }
+	auto norm = [](const float *u) { return std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]); };
+	auto major = [](const float *u) { int m = 0; for (int i = 1; i < 3; i++) if (std::fabs(u[i]) > std::fabs(u[m])) m = i; return m; };
+	a.lane_map = kLaneRows; a.phase_x = a.phase_y = 0;
+	const float dn = norm(d);
+	if (!(dn > 0.0f)) return;
+	if (std::fabs(d[major(d)]) > 0.98f * dn) a.lane_map = kLaneBlocks;
+	else {
+		const float nx = norm(sx), ny = norm(sy);
+		if (nx > 0.0f && ny > 0.0f && std::fabs(sy[2]) * nx < std::fabs(sx[2]) * ny) a.lane_map = kLaneColumns;
+	}
+	if (v.perspective) return;
+	// orthogonal view: every ray has the same direction; k at the middle of the central ray's path through the cube
+	float k_mid = 0.0f;
+	{
+		float k_in = -1e30f, k_out = 1e30f;
+		for (int i = 0; i < 3; i++) {
+			if (v.direction[i] == 0.0f) continue;
+			const float k1 = (-1.0f - v.origin[i]) / v.direction[i], k2 = (1.0f - v.origin[i]) / v.direction[i];
+			k_in = std::fmax(k_in, std::fmin(k1, k2)); k_out = std::fmin(k_out, std::fmax(k1, k2));
+		}
+		if (k_in < k_out && k_out < 1e29f) k_mid = 0.5f * (std::fmax(k_in, 0.0f) + k_out);
+	}
+	// texel coordinate of pixel g along the volume axis the screen direction mostly follows: t(g) = t0 + g * dt
+	auto best_phase = [&](const float *s, uint32_t first, uint32_t count, uint32_t centre) {
+		const int ax = major(s);
+		const float dt = s[ax];
+		const float t0 = std::fmaf(k_mid, d[ax], std::fmaf(v.origin[ax], half[ax], off[ax])) - dt * (float) centre;
+		const float hi = 2.0f * half[ax] - 1.0f;
+		uint32_t best = 0; long best_cost = -1;
+		for (uint32_t ph = 0; ph < 4; ph++) {
+			long cost = 0;
+			for (long g0 = -(long) ph; g0 < (long) count; g0 += 16) {        // every fourth group is plenty
+				long cell[4]; bool in[4];
+				for (int i = 0; i < 4; i++) {
+					const float t = t0 + dt * (float) ((long) first + g0 + i);
+					in[i] = g0 + i >= 0 && g0 + i < (long) count && t >= 0.0f && t <= hi;
+					cell[i] = (long) std::floor(t);
+				}
+				if (in[0] && in[3] && (cell[0] >> 1) != (cell[3] >> 1)) cost += 2;      // the group leaves its aligned cell pair
+				if (in[0] && in[1] && cell[0] != cell[1]) cost++;                         // a pixel pair straddles two cells
+				if (in[2] && in[3] && cell[2] != cell[3]) cost++;
+			}
+			if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ph; }
+		}
+		return best;
+	};
+	a.phase_x = best_phase(sx, a.p.x0, a.p.out_width, v.width / 2u);
+	// rows: local row ly maps to frame row gy; with bands of a multiple of 4 rows (or one band) gy = ly + const (mod 4)
+	const uint32_t gy0 = a.p.band_first * a.p.band_rows;
+	a.phase_y = best_phase(sy, gy0, a.p.out_rows < a.p.band_rows ? a.p.out_rows : a.p.band_rows, v.height / 2u);
+}
+
 int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
 	RayKernelArgs a;
 	memset(&a, 0, sizeof a);
@@ -136,6 +205,9 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		if ((bd & (bd - 1)) == 0) { a.esl_div_magic = 0; a.esl_div_shift = (uint32_t) __builtin_ctz(bd); }
 		else { a.esl_div_magic = (uint32_t) ((1ull << 32) / bd + 1); a.esl_div_shift = 0; }
 	}
+
+	if (c->tile_lane_map >= 0) { a.lane_map = (uint32_t) c->tile_lane_map; a.phase_x = c->tile_phase_x; a.phase_y = c->tile_phase_y; }
+	else choose_tile_mapping(a);
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
@@ -299,6 +371,14 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	c->force_wide = force;                       // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
+	return VR_OK;
+}
+
+int vr_hip_set_tile_mapping(vr_ctx *c, int32_t lane_map, uint32_t phase_x, uint32_t phase_y) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (lane_map < -1 || lane_map > (int32_t) kLaneBlocks || phase_x > 7u || phase_y > 7u)
+		return fail(c, VR_ERR_INVALID, "lane_map must be -1..2 and the phases 0..7");
+	c->tile_lane_map = lane_map; c->tile_phase_x = phase_x; c->tile_phase_y = phase_y;
 	return VR_OK;
 }
 

@@ -160,7 +160,11 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		}
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
 			f.w0 = *(const uint32_t *) q0;
+#ifdef VR_EXP_ONE_LOAD                               // measurement only (wrong images): what does the second load cost?
+			f.w1 = f.w0;
+#else
 			f.w1 = *(const uint32_t *) q1;
+#endif
 #ifdef VR_EXP_DUP_LOADS
 			{
 				uint64_t l0 = (uint64_t) q0, l1 = (uint64_t) q1;
@@ -403,27 +407,20 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		}
 	}
 
-	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16 pixels, 16 waves = 32x32.  Inside the wave each group of 16 consecutive lanes is a
-	//    4x4-pixel block (not two 8-pixel rows): the vector L1 coalesces per 16-lane group, and a compact block keeps the
-	//    group's samples inside the fewest 32-byte sectors whatever the view direction.
+	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16 pixels, 16 waves = 32x32.  Inside the wave each group of 16
+	//    consecutive lanes is a 4x4-pixel block (not two 8-pixel rows): a compact block keeps the group's samples inside the
+	//    fewest cache sectors whatever the view direction.
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#ifndef VR_LANE_GROUP
-#define VR_LANE_GROUP 0
-#endif
-#if VR_LANE_GROUP == 0          // 16-lane group = 4x4 pixels, wave = 2x2 groups = 8x8
 	const uint32_t qd = lane >> 4;
-	const uint32_t wx = (qd & 1u) * 4u + (lane & 3u), wy = (qd >> 1) * 4u + ((lane >> 2) & 3u);
-#elif VR_LANE_GROUP == 1        // row major 8x8: group = 8x2 pixels
-	const uint32_t wx = lane & 7u, wy = lane >> 3;
-#elif VR_LANE_GROUP == 2        // group = 2x8 pixels (column pairs)
-	const uint32_t qd = lane >> 4;
-	const uint32_t wx = qd * 2u + (lane & 1u), wy = (lane >> 1) & 7u;
-#elif VR_LANE_GROUP == 3        // 2x2 quads inside 4x4 groups (Z-order of lanes)
-	const uint32_t qd = lane >> 4;
-	const uint32_t wx = (qd & 1u) * 4u + ((lane >> 2) & 1u) * 2u + (lane & 1u), wy = (qd >> 1) * 4u + ((lane >> 3) & 1u) * 2u + ((lane >> 1) & 1u);
-#endif
-	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + wx;
-	const uint32_t ly = tile_y * (kThreads / 32u) + (wave >> 2) * 8u + wy;
+	// Order of the 16 lanes inside the group, picked per frame by the host (vr_hip_api.cpp choose_tile_mapping): the vector
+	// memory pipeline handles 4 consecutive lanes together and is fastest when their addresses share one aligned 16-byte
+	// chunk, so the 4 lanes should be the 4 pixels whose samples lie closest together in the brick order.
+	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;                             // kLaneRows: lanes run along screen x
+	if (a.lane_map == kLaneBlocks) { gu = ((lane >> 1) & 2u) | (lane & 1u); gv = ((lane >> 2) & 2u) | ((lane >> 1) & 1u); }
+	else if (a.lane_map == kLaneColumns) { const uint32_t t = gu; gu = gv; gv = t; }
+	const uint32_t wx = (qd & 1u) * 4u + gu, wy = (qd >> 1) * 4u + gv;
+	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + wx - a.phase_x;      // wraps for the pixels left of / below the buffer
+	const uint32_t ly = tile_y * (kThreads / 32u) + (wave >> 2) * 8u + wy - a.phase_y;
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
@@ -545,9 +542,21 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
 		// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
 		uint64_t live = __builtin_amdgcn_ballot_w64(alive);
+#ifndef VR_PREFETCH_DEPTH
+#define VR_PREFETCH_DEPTH 1
+#endif
+#if VR_PREFETCH_DEPTH == 2
+		float k1 = kx + step;                                  // k of the sample after the current one
+#endif
 		auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
+#if VR_PREFETCH_DEPTH == 2
+			const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
+			const float k2 = k1 + step;
+			nxt = issue(k2);
+#else
 			const float kn = kx + step;
 			nxt = issue(kn);
+#endif
 #ifndef VR_NO_SCHED_BARRIER
 			__builtin_amdgcn_sched_barrier(0);
 #endif
@@ -597,7 +606,18 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			}
 			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
 			kx = kn;
+#if VR_PREFETCH_DEPTH == 2
+			k1 = k2;
+#endif
 		};
+#if VR_PREFETCH_DEPTH == 2
+		TriFetch<BPV, LAYOUT> fa = issue(kx), fb = issue(k1), fc;
+		while (live != 0ull) {
+			step_sample(fa, fc);
+			step_sample(fb, fa);
+			step_sample(fc, fb);
+		}
+#else
 		TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
 		while (live != 0ull) {
 			step_sample(fa, fb);
@@ -605,6 +625,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			step_sample(fa, fb);                 // four samples per exit vote (-2.5 % against two)
 			step_sample(fb, fa);
 		}
+#endif
 	}
 
 	// -- RaycasterBase.h:44-50 write_color (+ the fused clear: misses and fully-empty rays store 0)
@@ -621,8 +642,8 @@ static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, 
                                  void *out, hipStream_t stream) {
 	constexpr uint32_t threads = LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)>::threads;
 	RayKernelArgs a = args;
-	a.tiles_x = (a.p.out_width + 31u) / 32u;
-	a.tiles_y = (a.p.out_rows + threads / 32u - 1u) / (threads / 32u);
+	a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
+	a.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
 	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), 0, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();

@@ -74,6 +74,10 @@ class HipRenderer:
         """Testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path (what volumes > 1024^3 use), 0/False = automatic."""
         self._check(self._L.vr_hip_set_wide_addressing(self._ctx, int(force)), "set_wide_addressing")
 
+    def set_tile_mapping(self, lane_map=-1, phase_x=0, phase_y=0):
+        """Lane order inside a 4x4-pixel block (-1 automatic, 0 rows, 1 columns, 2 2x2 blocks) and tile-grid phase; speed only."""
+        self._check(self._L.vr_hip_set_tile_mapping(self._ctx, int(lane_map), int(phase_x), int(phase_y)), "set_tile_mapping")
+
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
         k = {"shell": 0, "noise": 1}[kind]
