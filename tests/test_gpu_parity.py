@@ -129,7 +129,7 @@ def test_wide_addressing_path(vr, gpu, golden, oracle):
                         p = golden.params(case, mode)
                         gpu.set_wide_addressing(False)
                         narrow = gpu.render_volume(p)
-                        for force in (1, 2):       # arithmetic 64-bit path, table path with 64-bit z offsets
+                        for force in (1, 2, 4, 6):  # arithmetic 64-bit path, table path with 64-bit z offsets, + clamped fetch
                             gpu.set_wide_addressing(force)
                             wide = gpu.render_volume(p)
                             assert np.array_equal(narrow, wide), (vox.dtype, layout, case["label"], mode, force)

@@ -33,6 +33,7 @@ struct RayKernelArgs {
 	uint32_t skip_mask;                // per-voxel bit mask ~(skip_below - 1), replicated over the packed word: all 8 corners below the
 	                                   // power of two skip_below => TF coordinate <= tf_zero_below
 	uint32_t skip_never;               // 1 when the TF has no leading zero entries (the corner test must always fail), else 0
+	uint32_t clamp_fetch;              // 1: clamp the fetch coordinates of every sample (views whose fp32 coordinates may leave (-1, N))
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes

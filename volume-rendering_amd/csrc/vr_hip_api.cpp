@@ -8,6 +8,7 @@
 // the kernel (no cudaMemset per frame, GPURenderer1.cu:107).  There is no CPU fallback.
 #include "vr_device.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,6 +42,7 @@ struct vr_ctx {
 	void *vol_bricked = nullptr;            // TRILINEAR copy in the bricked layout (vr_device.h), built by set_volume
 	uint32_t layout = VR_LAYOUT_BRICKED;
 	uint32_t force_wide = 0;
+	uint32_t force_clamp_fetch = 0;              // testing aid (vr_hip_set_wide_addressing bit 2)
 	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
 	uint32_t tile_phase_x = 0, tile_phase_y = 0;
 	// feeders scratch
@@ -118,7 +120,10 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 //    pitch is commensurate with the voxel grid — the reference's default zoom — every quad then reads a single chunk).
 void choose_tile_mapping(RayKernelArgs &a) {
 	const vr_view &v = a.p.view;
-	const float half[3] = { a.half_x, a.half_y, a.half_z }, off[3] = { a.off_x, a.off_y, a.off_z };
+	// voxel-cell coordinate of a position p: TRILINEAR p * N/2 + N/2 - 1/2 (texel space), NEAREST (p + 1) / 2 * N (ModelBase.h:17-23)
+	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
+	const float half[3] = { a.half_x, a.half_y, a.half_z };
+	const float off[3] = { nearest ? a.half_x : a.off_x, nearest ? a.half_y : a.off_y, nearest ? a.half_z : a.off_z };
 	float d[3], sx[3], sy[3];
 	for (int i = 0; i < 3; i++) { d[i] = v.direction[i] * half[i]; sx[i] = v.right_plane[i] * half[i]; sy[i] = v.up_plane[i] * half[i]; }
 	auto norm = [](const float *u) { return std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]); };
@@ -195,6 +200,13 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		if (below == 0) a.skip_mask = 0xffffffffu;
 		else if (c->bpv == 1) a.skip_mask = ((0xffu & ~(below - 1u)) * 0x01010101u);
 		else a.skip_mask = ((0xffffu & ~(below - 1u)) * 0x00010001u);
+	}
+	{   // In-cube sample coordinates are exact to ~2^-23 * (1 + 2 max|origin|) * N/2 texels; the unclamped fetch (vr_kernels.hip)
+		// needs them inside (-1, N), i.e. an error below 1/2.  Keep a factor-4 margin, else clamp every sample.
+		const float omax = std::fmax(std::fabs(p->view.origin[0]), std::fmax(std::fabs(p->view.origin[1]), std::fabs(p->view.origin[2])));
+		const float nmax = (float) std::max(c->dim[0], std::max(c->dim[1], c->dim[2]));
+		a.clamp_fetch = (1.0f + 2.0f * omax) * nmax < 1048576.0f ? 0u : 1u;
+		if (c->force_clamp_fetch) a.clamp_fetch = 1u;
 	}
 	a.force_wide = c->force_wide;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
@@ -370,7 +382,8 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 
 int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	c->force_wide = force;                       // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
+	c->force_wide = force & 3u;                  // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
+	c->force_clamp_fetch = (force >> 2) & 1u;    // + 4: clamp the fetch coordinates of every sample (far-away views do that)
 	return VR_OK;
 }
 

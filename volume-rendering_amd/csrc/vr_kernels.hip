@@ -119,21 +119,27 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	// bricked: slice z quad, slice z+1 quad (u8: one dword each, u16: two dwords each);
 	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
 	uint32_t w0, w1, w2, w3;
-	float ax, ay, az;
+	float xb, yb, zb;                                // texel-space coordinates of the sample (clamped in tri_resolve)
 #ifdef VR_EXP_DUP_LOADS
 	uint32_t d0, d1;                                 // measurement only: the same two loads issued a second time (L1 hits)
 #endif
 };
 
+// `clamp` (wave-uniform) = false is allowed for positions INSIDE the volume's cube, i.e. coordinates in (-1, N): there
+// truncation toward zero already yields the clamped cell (x in (-1, 0) -> 0 like clamp-to-0; x in (N-1, N) -> N-1 like
+// clamp-to-N-1), so the three v_med3 are only needed for the interpolation weights, and those are computed in
+// tri_resolve, which most samples of a sparse volume never reach (transparent shortcut of the ray loop).
 template <int BPV, int ADDR, int LAYOUT>
 __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
-                                                           float xb, float yb, float zb) {
+                                                           float xb, float yb, float zb, bool clamp) {
 	TriFetch<BPV, LAYOUT> f;
-	xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
-	yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
-	zb = __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
+	f.xb = xb; f.yb = yb; f.zb = zb;
+	if (clamp) {
+		xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
+		yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
+		zb = __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
+	}
 	const uint32_t ix = (uint32_t) (int) xb, iy = (uint32_t) (int) yb, iz = (uint32_t) (int) zb;
-	f.ax = __builtin_amdgcn_fractf(xb); f.ay = __builtin_amdgcn_fractf(yb); f.az = __builtin_amdgcn_fractf(zb);
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
 	if (LAYOUT == kLayoutBricked) {
 		constexpr uint32_t kElem = 4 * BPV;
@@ -202,7 +208,10 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 
 // returns the interpolated RAW voxel value
 template <int BPV, int LAYOUT>
-__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f) {
+__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a) {
+	const float ax = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.xb, 0.0f, a.max_x));
+	const float ay = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.yb, 0.0f, a.max_y));
+	const float az = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.zb, 0.0f, a.max_z));
 	float v000, v100, v010, v110, v001, v101, v011, v111;
 	if (LAYOUT == kLayoutBricked) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
@@ -221,10 +230,10 @@ __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f) {
 			v001 = (float) (f.w2 & 0xffffu); v101 = (float) (f.w2 >> 16); v011 = (float) (f.w3 & 0xffffu); v111 = (float) (f.w3 >> 16);
 		}
 	}
-	const float c00 = lerp(v000, v100, f.ax), c10 = lerp(v010, v110, f.ax);
-	const float c01 = lerp(v001, v101, f.ax), c11 = lerp(v011, v111, f.ax);
-	const float c0 = lerp(c00, c10, f.ay), c1 = lerp(c01, c11, f.ay);
-	return lerp(c0, c1, f.az);
+	const float c00 = lerp(v000, v100, ax), c10 = lerp(v010, v110, ax);
+	const float c01 = lerp(v001, v101, ax), c11 = lerp(v011, v111, ax);
+	const float c0 = lerp(c00, c10, ay), c1 = lerp(c01, c11, ay);
+	return lerp(c0, c1, az);
 }
 
 // x where the wave mask has the lane's bit set, 0 elsewhere: one v_cndmask with the mask taken straight from SGPRs
@@ -526,106 +535,117 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		}
 	} else {
 		// texel-space ray: coordinate = fma(k, A, B) (see oracle/vr_oracle.c axis_setup)
-		const f3 A = mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z);
-		const f3 B = mk3(VR_FMA(origin.x, a.half_x, a.off_x), VR_FMA(origin.y, a.half_y, a.off_y), VR_FMA(origin.z, a.half_z, a.off_z));
-		// Lanes that are finished keep executing the (clamped, always in-bounds) fetch with a zero weight instead of being
-		// masked off: acc = fma(cur, 0, acc) leaves them bit-for-bit unchanged, and the loop body needs no per-lane
-		// control flow except the shading block.  The wave leaves when no lane is alive.
-		// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited, so one
-		// memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).  The
-		// body is written once (`step_sample`) and instantiated twice per iteration with the two fetch slots swapped: no
-		// register copies, one exit vote per four samples (a finished wave at worst composites three more weight-0 samples).
-		auto issue = [&](float k) {
-			return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z));
-		};
-		// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
-		// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
-		// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
-		uint64_t live = __builtin_amdgcn_ballot_w64(alive);
+		f3 A = mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z);
+		f3 B = mk3(VR_FMA(origin.x, a.half_x, a.off_x), VR_FMA(origin.y, a.half_y, a.off_y), VR_FMA(origin.z, a.half_z, a.off_z));
+		// Lanes that are finished keep executing an in-bounds fetch with a zero weight instead of being masked off:
+		// acc = fma(cur, 0, acc) leaves them bit-for-bit unchanged, and the loop body needs no per-lane control flow
+		// except the shading block.  The wave leaves when no lane is alive.
+		// In bounds without clamping three coordinates per sample: every fetch position is taken at min(k, ky), i.e. on the
+		// ray's own segment inside the cube, where truncation alone gives the clamped cell (tri_issue); lanes that never
+		// had a segment march the constant position 0.  The host switches the coordinate clamp back on (clamp_fetch) for
+		// views so far from the volume that fp32 rounding of the coordinates could leave (-1, N).
+		if (!alive) { kx = 0.0f; ky = 0.0f; A = mk3(0.0f, 0.0f, 0.0f); B = A; }
+		auto march = [&](auto clamp_tag) {                    // instantiated for both settings: no per-sample test of the flag
+			constexpr bool kClamp = decltype(clamp_tag)::value;
+			// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited, so one
+			// memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).  The
+			// body is written once (`step_sample`) and instantiated twice per iteration with the two fetch slots swapped: no
+			// register copies, one exit vote per four samples (a finished wave at worst composites three more weight-0 samples).
+			auto issue = [&](float k) {
+				if (!kClamp) k = __builtin_fminf(k, ky);
+				return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
+			};
+			const uint64_t skip_never = a.skip_never ? ~0ull : 0ull;
+			// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
+			// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
+			// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
+			uint64_t live = __builtin_amdgcn_ballot_w64(alive);
 #ifndef VR_PREFETCH_DEPTH
 #define VR_PREFETCH_DEPTH 1
 #endif
 #if VR_PREFETCH_DEPTH == 2
-		float k1 = kx + step;                                  // k of the sample after the current one
+			float k1 = kx + step;                                  // k of the sample after the current one
 #endif
-		auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
+			auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
 #if VR_PREFETCH_DEPTH == 2
-			const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
-			const float k2 = k1 + step;
-			nxt = issue(k2);
+				const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
+				const float k2 = k1 + step;
+				nxt = issue(k2);
 #else
-			const float kn = kx + step;
-			nxt = issue(kn);
+				const float kn = kx + step;
+				nxt = issue(kn);
 #endif
 #ifndef VR_NO_SCHED_BARRIER
-			__builtin_amdgcn_sched_barrier(0);
+				__builtin_amdgcn_sched_barrier(0);
 #endif
-			// Exact shortcuts, decided per wave.  Entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
-			// default TF is zero below 10 % density), so a sample whose TF coordinate tb is <= tf_zero_below has colour
-			// (0,0,0,0), is never shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.
-			//  (1) before any arithmetic: if all 8 corner voxels of every live lane are below the power of two `skip_below`
-			//      (a bit test on the packed words), the interpolated value is too — a lerp never leaves [min, max] of its
-			//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
-			//      follows: the wave skips unpacking, the 7 lerps and everything after them;
-			//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
+				// Exact shortcuts, decided per wave.  Entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
+				// default TF is zero below 10 % density), so a sample whose TF coordinate tb is <= tf_zero_below has colour
+				// (0,0,0,0), is never shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.
+				//  (1) before any arithmetic: if all 8 corner voxels of every live lane are below the power of two `skip_below`
+				//      (a bit test on the packed words), the interpolated value is too — a lerp never leaves [min, max] of its
+				//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
+				//      follows: the wave skips unpacking, the 7 lerps and everything after them;
+				//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
 #ifdef VR_EXP_DUP_LOADS
-			if (LAYOUT == kLayoutBricked && BPV == 1) asm volatile("" :: "v"(cur.d0), "v"(cur.d1));
+				if (LAYOUT == kLayoutBricked && BPV == 1) asm volatile("" :: "v"(cur.d0), "v"(cur.d1));
 #endif
-			uint32_t corners;
-			if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
-			else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
-			if ((__builtin_amdgcn_uicmp((corners & a.skip_mask) | a.skip_never, 0u, kIcmpNE) & live) != 0ull) {
-			const float raw = tri_resolve<BPV, LAYOUT>(cur);                                       // GPURenderer4.cu:76
-			// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
-			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-			if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
-				f4 c;
-				{
-					const uint32_t i = (uint32_t) (int) tb;
-					const float w = __builtin_amdgcn_fractf(tb);
-					const f4 c0 = lds.tf[i], dc = lds.dtf[i];
-					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
-					c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
+				uint32_t corners;
+				if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
+				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
+				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull) {
+				const float raw = tri_resolve<BPV, LAYOUT>(cur, a);                                    // GPURenderer4.cu:76
+				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
+				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+				if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
+					f4 c;
+					{
+						const uint32_t i = (uint32_t) (int) tb;
+						const float w = __builtin_amdgcn_fractf(tb);
+						const f4 c0 = lds.tf[i], dc = lds.dtf[i];
+						c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
+						c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
+					}
+					const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
+					if (shaded != 0ull) {                                                              // GPURenderer4.cu:41-51 shade_texture
+						const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
+						const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
+						const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
+						const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
+						const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
+						                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb), true), a);
+						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
+						c.x += diffuse; c.y += diffuse; c.z += diffuse;
+					}
+					const float t = select_lanes(live, 1 - acc.w);                                     // finished lanes: weight 0
+					acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
+					acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
+					live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                        // ERT (CPURenderer.cpp:35-36)
 				}
-				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
-				if (shaded != 0ull) {                                                              // GPURenderer4.cu:41-51 shade_texture
-					const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
-					const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
-					const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
-					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-					const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
-					                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb)));
-					const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
-					c.x += diffuse; c.y += diffuse; c.z += diffuse;
 				}
-				const float t = select_lanes(live, 1 - acc.w);                                     // finished lanes: weight 0
-				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
-				acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
-				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                        // ERT (CPURenderer.cpp:35-36)
-			}
-			}
-			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
-			kx = kn;
+				live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
+				kx = kn;
 #if VR_PREFETCH_DEPTH == 2
-			k1 = k2;
+				k1 = k2;
+#endif
+			};
+#if VR_PREFETCH_DEPTH == 2
+			TriFetch<BPV, LAYOUT> fa = issue(kx), fb = issue(k1), fc;
+			while (live != 0ull) {
+				step_sample(fa, fc);
+				step_sample(fb, fa);
+				step_sample(fc, fb);
+			}
+#else
+			TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
+			while (live != 0ull) {
+				step_sample(fa, fb);
+				step_sample(fb, fa);
+				step_sample(fa, fb);                 // four samples per exit vote (-2.5 % against two)
+				step_sample(fb, fa);
+			}
 #endif
 		};
-#if VR_PREFETCH_DEPTH == 2
-		TriFetch<BPV, LAYOUT> fa = issue(kx), fb = issue(k1), fc;
-		while (live != 0ull) {
-			step_sample(fa, fc);
-			step_sample(fb, fa);
-			step_sample(fc, fb);
-		}
-#else
-		TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
-		while (live != 0ull) {
-			step_sample(fa, fb);
-			step_sample(fb, fa);
-			step_sample(fa, fb);                 // four samples per exit vote (-2.5 % against two)
-			step_sample(fb, fa);
-		}
-#endif
+		if (a.clamp_fetch) march(std::true_type()); else march(std::false_type());
 	}
 
 	// -- RaycasterBase.h:44-50 write_color (+ the fused clear: misses and fully-empty rays store 0)
