@@ -53,9 +53,9 @@ typedef enum vr_sampling {
 typedef enum vr_layout {
 	VR_LAYOUT_LINEAR  = 0,    /* x-fastest linear array exactly as Model::data (ModelBase.h:18-22) */
 	VR_LAYOUT_BRICKED = 1     /* default: "quad bricks" — every element packs the 2x2 (x,y) voxel neighbourhood of a slice into
-	                             one aligned word, stored in 8x8x(8+1)-element bricks: a trilinear sample is two aligned loads
-	                             from one brick and the cache-line footprint no longer depends on the view direction
-	                             (4.5x the voxel bytes in HBM; volume-rendering_amd/csrc/vr_device.h) */
+	                             one aligned word, stored in 8x8x8-element bricks: a trilinear sample is two aligned loads
+	                             and the cache-line footprint no longer depends on the view direction
+	                             (4x the voxel bytes in HBM; volume-rendering_amd/csrc/vr_device.h) */
 } vr_layout;
 
 /* struct View, ViewBase.h:14-21 (dims widened to 32 bit, bool -> uint32) */

@@ -46,12 +46,12 @@ struct RayKernelArgs {
 //                   4x an aligned one, and a wave that touches n cache lines pays ~n cycles in the L1 tag pipe.
 //   kLayoutBricked: "quad bricks".  Element (x,y,z) packs the 2x2 (x,y) neighbourhood {v(x,y), v(x+1,y), v(x,y+1),
 //                   v(x+1,y+1)} of slice z (indices clamped at the upper faces, where the weight is exactly 0) into one
-//                   naturally ALIGNED 4-byte (u8) / 8-byte (u16) word.  Elements are stored in bricks of 8x8x8 positions,
-//                   Z-ORDER (Morton) inside the brick: element offset = dilate(z&7) | dilate(x&7) << 1 | dilate(y&7) << 2,
-//                   so every aligned 32-byte sector holds a 2x2x2 block of elements and every 128-byte line a 4x4x2 block.
-//                   A trilinear sample is TWO aligned loads (slices z and z+1); the vector L1 pays about one cycle per
-//                   distinct 32-byte sector a 16-lane group touches (scripts/ubench/tcp_coalesce.hip), and with this
-//                   layout that count no longer depends on the view direction.  Costs 4x the voxel bytes in HBM.
+//                   naturally ALIGNED 4-byte (u8) / 8-byte (u16) word.  Elements are stored in bricks of 8x8x8 positions;
+//                   the order inside a brick is kBrickBits below.  A trilinear sample is TWO aligned loads (slices z and
+//                   z+1); the vector memory pipeline serves a gather one lane quad at a time and is fastest when the
+//                   quad's four addresses share an aligned 16-byte chunk (scripts/ubench/tcp_coalesce.hip), which is
+//                   what the brick order and the lane order of the ray-march kernel are chosen for.  Costs 4x the voxel
+//                   bytes in HBM.
 enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1 };
 enum : uint32_t { kLaneRows = 0, kLaneColumns = 1, kLaneBlocks = 2 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
