@@ -97,6 +97,30 @@ int main() {
 			snprintf(name, sizeof name, "H: headline tile at pixel %d, %s, plane %d", phase, oname[o], plane); run(buf, out, d_off, h, name);
 		}
 	}
+	// I: final brick order (x0 y0 | x1 y1 | z0 | x2 y2 | z1 z2), tile aligned to even cells (2 pixels per cell), the three lane
+	// orders of the kernel (rows / columns / 2x2 blocks) on the three axis planes (screen x -> first axis, screen y -> second)
+	{
+		const int order[9] = { 0, 2, 5, 1, 3, 6, 4, 7, 8 };
+		auto spread = [&](int v, int axis) { return ((v & 1) << order[3 * axis]) | (((v >> 1) & 1) << order[3 * axis + 1]) | (((v >> 2) & 1) << order[3 * axis + 2]); };
+		const char *mname[3] = { "rows   ", "columns", "blocks " };
+		const int planes[3][2] = { { 0, 1 }, { 0, 2 }, { 2, 1 } };           // (x,y) (x,z) (z,y)
+		const char *pname[3] = { "(x,y)", "(x,z)", "(z,y)" };
+		for (int pl = 0; pl < 3; pl++) for (int map = 0; map < 3; map++) for (int second = 0; second < 2; second++) {
+			for (int l = 0; l < 64; l++) {
+				const int qd = l >> 4;
+				int gu = l & 3, gv = (l >> 2) & 3;
+				if (map == 2) { gu = ((l >> 1) & 2) | (l & 1); gv = ((l >> 2) & 2) | ((l >> 1) & 1); }
+				else if (map == 1) { const int t = gu; gu = gv; gv = t; }
+				const int i = (qd & 1) * 4 + gu, j = (qd >> 1) * 4 + gv;
+				int c[3] = { 3, 3, 3 };
+				c[planes[pl][0]] = (16 + i) >> 1; c[planes[pl][1]] = (16 + j) >> 1;
+				c[2] += second;                                              // the z+1 load of the same sample
+				const int brick = (c[2] >> 3) * 4 + (c[1] >> 3) * 2 + (c[0] >> 3);
+				h[l] = (brick * 512 + (spread(c[0] & 7, 0) | spread(c[1] & 7, 1) | spread(c[2] & 7, 2))) * 4;
+			}
+			snprintf(name, sizeof name, "I: plane %s, %s, %s load", pname[pl], mname[map], second ? "z+1" : "z  "); run(buf, out, d_off, h, name);
+		}
+	}
 	// all lanes same dword
 	for (int l = 0; l < 64; l++) h[l] = 0; run(buf, out, d_off, h, "F: all lanes one dword");
 	return 0;

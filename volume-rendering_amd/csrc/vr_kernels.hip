@@ -104,6 +104,15 @@ __device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKer
 	return fetch_voxel<BPV, ADDR, LAYOUT>(vol, a, lut, ix, iy, iz);
 }
 
+// The same voxel for a position INSIDE the cube (pos + 1 >= -1e-6): no lower clamp (a fraction above -1 truncates to 0),
+// and ((pos + 1) * 0.5f) * n == (pos + 1) * (0.5f * n) bit for bit, because both scalings by 0.5 are exact.
+template <int BPV, int ADDR, int LAYOUT>
+__device__ __forceinline__ uint32_t sample_nearest_incube(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 pos) {
+	const int iz = (int) ((pos.z + 1) * a.half_z), iy = (int) ((pos.y + 1) * a.half_y), ix = (int) ((pos.x + 1) * a.half_x);
+	const int mz = (int) a.dim_z - 1, my = (int) a.dim_y - 1, mx = (int) a.dim_x - 1;
+	return fetch_voxel<BPV, ADDR, LAYOUT>(vol, a, lut, (uint32_t) (ix < mx ? ix : mx), (uint32_t) (iy < my ? iy : my), (uint32_t) (iz < mz ? iz : mz));
+}
+
 __device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
 
 // ---- manual trilinear fetch, split in two so that the ray-march loop can software-pipeline it -----------------------
@@ -495,12 +504,21 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// Same loop shape as the TRILINEAR branch below (prefetch of sample i+1, finished lanes composited with weight 0,
 		// per-wave transparent-sample shortcut, two samples per exit vote); the arithmetic is the reference's, unfused:
 		// acc + cur * 0 == acc exactly, and map_float_int clamps every index, so speculative fetches stay in bounds.
+		// In-bounds speculative fetches without clamping to 0: every fetch position is taken at min(k, ky), on the ray's own
+		// segment inside the cube (for live lanes that IS the sample position); lanes without a segment march position 0.
+		// clamp_fetch (far-away views, see TRILINEAR) falls back to the reference's two-sided clamp.
 		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
 		uint64_t live = __builtin_amdgcn_ballot_w64(alive);            // liveness as one scalar wave mask (see TRILINEAR)
+		if (!alive) { kx = 0.0f; ky = 0.0f; origin = mk3(0.0f, 0.0f, 0.0f); dir = origin; pt = origin; }
+		auto march = [&](auto clamp_tag) {
+		constexpr bool kClamp = decltype(clamp_tag)::value;
+		auto fetch = [&](f3 p) {
+			return kClamp ? sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, p) : sample_nearest_incube<BPV, ADDR, LAYOUT>(vol, a, lut, p);
+		};
 		auto step_sample = [&](const uint32_t &cur_s, uint32_t &nxt_s) {
 			const float kn = kx + step;
-			const f3 pn = march_point<SAMPLING>(origin, dir, kn);
-			nxt_s = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pn);
+			const f3 pn = march_point<SAMPLING>(origin, dir, kClamp ? kn : __builtin_fminf(kn, ky));
+			nxt_s = fetch(pn);
 			__builtin_amdgcn_sched_barrier(0);
 			const uint32_t s = cur_s;
 			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
@@ -526,13 +544,15 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			kx = kn;
 			pt = pn;
 		};
-		uint32_t sa = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, pt), sb = 0;
+		uint32_t sa = fetch(pt), sb = 0;
 		while (live != 0ull) {
 			step_sample(sa, sb);
 			step_sample(sb, sa);
 			step_sample(sa, sb);
 			step_sample(sb, sa);
 		}
+		};
+		if (a.clamp_fetch) march(std::true_type()); else march(std::false_type());
 	} else {
 		// texel-space ray: coordinate = fma(k, A, B) (see oracle/vr_oracle.c axis_setup)
 		f3 A = mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z);
