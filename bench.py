@@ -216,12 +216,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     tm = r.timing()
+    per_rank_kernel_ms = [tm.kernel_ms_sum / max(1, tm.launches)]
     if distributed:
-        t = torch.tensor([elapsed, tm.kernel_ms_sum / max(1, tm.launches)], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        t = torch.tensor([elapsed, per_rank_kernel_ms[0]], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                   # scaling is set by load balance — report every rank's kernel time
+        per_rank_kernel_ms = [float(e[1]) for e in every]
+        elapsed, kernel_ms = max(float(e[0]) for e in every), max(per_rank_kernel_ms)
     else:
-        kernel_ms = tm.kernel_ms_sum / max(1, tm.launches)
+        kernel_ms = per_rank_kernel_ms[0]
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -243,6 +246,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": recorded_traffic(f"{a.mode}_{a.sampling}_{n}_{W}_n{world}"), "kernel": "vr::raymarch_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
+                         "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
                          "note": "full march is gather/VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling')"},
             "minmax_feeder": {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
                               "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),

@@ -54,3 +54,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "vr_oracle" not in text.replace("oracle/vr_oracle.c", "") and "libvolr_ref" not in text, os.path.join(dirpath, f)
+
+
+def test_hot_kernels_keep_eight_waves_per_simd(vr):
+    """The ray-march variants the product launches by default (bricked layout, table addressing) must stay within 80 SGPRs and
+    64 VGPRs: on gfx950 a SIMD then holds 8 of their waves; 81-96 SGPRs silently drop that to 7, i.e. from 4 to 3 resident
+    workgroups per CU (measured: +3 % frame time).  Figures come from the build's -Rpass-analysis log."""
+    import subprocess
+    csrc = os.path.join(ROOT, "volume-rendering_amd", "csrc")
+    log = os.path.join(csrc, "resource_usage.log")
+    if not os.path.exists(log):
+        subprocess.check_call(["make", "-B", "-C", csrc])
+    text = open(log).read()
+    found = 0
+    for m in re.finditer(r"Function Name: (\S*raymarch_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)E\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?"
+                         r"ScratchSize \[bytes/lane\]: (\d+)", text, flags=re.S):
+        sampling, bpv, addr, layout = (int(m.group(i)) for i in (2, 3, 4, 5))
+        sgprs, vgprs, scratch = int(m.group(6)), int(m.group(7)), int(m.group(8))
+        assert scratch == 0, (m.group(1), "spills to scratch")
+        if layout == 1 and addr in (0, 1):
+            found += 1
+            assert sgprs <= 80 and vgprs <= 64, (m.group(1), sgprs, vgprs)
+    assert found == 8, found

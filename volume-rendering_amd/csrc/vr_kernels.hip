@@ -309,9 +309,21 @@ __device__ __forceinline__ float leap_empty_space(const RayKernelArgs &a, BlockI
 	if (dir.x > 0) ix++;
 	if (dir.y > 0) iy++;
 	if (dir.z > 0) iz++;
-	f3 kp = mk3(((-1.0f + a.p.esl_block_size[0] * (float) ix) - pt.x) / dir.x,
-	            ((-1.0f + a.p.esl_block_size[1] * (float) iy) - pt.y) / dir.y,
-	            ((-1.0f + a.p.esl_block_size[2] * (float) iz) - pt.z) / dir.z);
+	const f3 num = mk3((-1.0f + a.p.esl_block_size[0] * (float) ix) - pt.x, (-1.0f + a.p.esl_block_size[1] * (float) iy) - pt.y,
+	                   (-1.0f + a.p.esl_block_size[2] * (float) iz) - pt.z);
+	// Exact shortcut: a quotient num / dir is <= 0 when num is 0 (and dir is not) or when the signs differ, and one
+	// non-positive quotient makes dk = max(min(..), 0) = 0, i.e. a leap of floor(0 / step) * step = 0 — no division needed.
+	// That is the steady state of a ray that runs exactly along a block face (axis-aligned views): it probes every step.
+	// The sign test is the product num * dir < 0 (a product that underflows to 0 just takes the division path), kept in
+	// VGPR arithmetic: per-axis lane masks would cost SGPRs, and above 80 of them a SIMD holds 7 waves instead of 8.
+	{
+		const float sx = num.x == 0 ? -__builtin_fabsf(dir.x) : num.x * dir.x;
+		const float sy = num.y == 0 ? -__builtin_fabsf(dir.y) : num.y * dir.y;
+		const float sz = num.z == 0 ? -__builtin_fabsf(dir.z) : num.z * dir.z;
+		if (__builtin_fminf(__builtin_fminf(sx, sy), sz) < 0)
+			return 0.0f;
+	}
+	f3 kp = mk3(num.x / dir.x, num.y / dir.y, num.z / dir.z);
 	if (dir.x == 0) kp.x = 100;
 	if (dir.y == 0) kp.y = 100;
 	if (dir.z == 0) kp.z = 100;
@@ -583,6 +595,11 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #ifndef VR_PREFETCH_DEPTH
 #define VR_PREFETCH_DEPTH 1
 #endif
+#define VR_STR2(x) #x
+#define VR_STR(x) VR_STR2(x)
+#ifndef VR_LOOP_SHIFT
+#define VR_LOOP_SHIFT 0
+#endif
 #if VR_PREFETCH_DEPTH == 2
 			float k1 = kx + step;                                  // k of the sample after the current one
 #endif
@@ -657,6 +674,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			}
 #else
 			TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
+#ifdef VR_LOOP_ALIGN                                  // measurement aid: code alignment of the sample loop (+ VR_LOOP_SHIFT bytes)
+			asm volatile(".p2align " VR_STR(VR_LOOP_ALIGN) "\n\t.rept " VR_STR(VR_LOOP_SHIFT) "\n\ts_nop 0\n\t.endr");
+#endif
 			while (live != 0ull) {
 				step_sample(fa, fb);
 				step_sample(fb, fa);
