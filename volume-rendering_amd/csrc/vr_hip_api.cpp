@@ -45,6 +45,9 @@ struct vr_ctx {
 	uint32_t force_clamp_fetch = 0;              // testing aid (vr_hip_set_wide_addressing bit 2)
 	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
 	uint32_t tile_phase_x = 0, tile_phase_y = 0;
+	// the last few automatic choices, keyed by the frame parameters and the volume size (a benchmark cycles 8 views)
+	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y; };
+	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -219,7 +222,20 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 
 	if (c->tile_lane_map >= 0) { a.lane_map = (uint32_t) c->tile_lane_map; a.phase_x = c->tile_phase_x; a.phase_y = c->tile_phase_y; }
-	else choose_tile_mapping(a);
+	else {
+		vr_ctx::MapEntry *hit = nullptr;
+		for (uint32_t i = 0; i < c->map_cached && hit == nullptr; i++)
+			if (memcmp(&c->map_cache[i].p, p, sizeof *p) == 0 && memcmp(c->map_cache[i].dim, c->dim, sizeof c->dim) == 0) hit = &c->map_cache[i];
+		if (hit == nullptr) {
+			choose_tile_mapping(a);
+			hit = &c->map_cache[c->map_next];
+			c->map_next = (c->map_next + 1) % 16u;
+			if (c->map_cached < 16u) c->map_cached++;
+			hit->p = *p; memcpy(hit->dim, c->dim, sizeof c->dim);
+			hit->lane_map = a.lane_map; hit->phase_x = a.phase_x; hit->phase_y = a.phase_y;
+		}
+		a.lane_map = hit->lane_map; a.phase_x = hit->phase_x; a.phase_y = hit->phase_y;
+	}
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
