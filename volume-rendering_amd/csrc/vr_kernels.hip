@@ -595,11 +595,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #ifndef VR_PREFETCH_DEPTH
 #define VR_PREFETCH_DEPTH 1
 #endif
-#define VR_STR2(x) #x
-#define VR_STR(x) VR_STR2(x)
-#ifndef VR_LOOP_SHIFT
-#define VR_LOOP_SHIFT 0
-#endif
 #if VR_PREFETCH_DEPTH == 2
 			float k1 = kx + step;                                  // k of the sample after the current one
 #endif
@@ -674,9 +669,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			}
 #else
 			TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
-#ifdef VR_LOOP_ALIGN                                  // measurement aid: code alignment of the sample loop (+ VR_LOOP_SHIFT bytes)
-			asm volatile(".p2align " VR_STR(VR_LOOP_ALIGN) "\n\t.rept " VR_STR(VR_LOOP_SHIFT) "\n\ts_nop 0\n\t.endr");
-#endif
 			while (live != 0ull) {
 				step_sample(fa, fb);
 				step_sample(fb, fa);
