@@ -121,6 +121,26 @@ int main() {
 			snprintf(name, sizeof name, "I: plane %s, %s, %s load", pname[pl], mname[map], second ? "z+1" : "z  "); run(buf, out, d_off, h, name);
 		}
 	}
+	// J: how the cost grows with the number of lane quads that straddle two 16-byte chunks (k of 16 quads); the other
+	// quads read one chunk each.  "near": the second chunk is 16 B away in the same sector; "far": in another 128-byte line
+	for (int far = 0; far < 2; far++) for (int k : {0, 1, 2, 4, 8, 12, 16}) {
+		for (int l = 0; l < 64; l++) {
+			const int q = l >> 2, i = l & 3;
+			h[l] = q * 32 + (i & 1) * 4;                                      // quad q: two dwords of chunk 2q
+			if (q < k && i >= 2) h[l] += far ? 4096 : 16;                     // lanes 2,3 of a split quad: another chunk
+		}
+		snprintf(name, sizeof name, "J: %2d of 16 quads straddle two chunks (%s)", k, far ? "far" : "near"); run(buf, out, d_off, h, name);
+	}
+	// K: quads whose four lanes read 1, 2 or 4 distinct dwords of ONE chunk, and 4 dwords of 4 different chunks of one line
+	for (int v = 0; v < 4; v++) {
+		for (int l = 0; l < 64; l++) {
+			const int q = l >> 2, i = l & 3;
+			if (v == 0) h[l] = q * 16; else if (v == 1) h[l] = q * 16 + (i & 1) * 4; else if (v == 2) h[l] = q * 16 + i * 4;
+			else h[l] = (q >> 1) * 128 + (q & 1) * 4 + i * 16;
+		}
+		const char *kn[4] = { "1 dword per quad", "2 dwords of one chunk", "4 dwords of one chunk", "4 chunks of one line per quad" };
+		snprintf(name, sizeof name, "K: %s", kn[v]); run(buf, out, d_off, h, name);
+	}
 	// all lanes same dword
 	for (int l = 0; l < 64; l++) h[l] = 0; run(buf, out, d_off, h, "F: all lanes one dword");
 	return 0;
