@@ -57,24 +57,30 @@ enum : uint32_t { kLaneRows = 0, kLaneColumns = 1, kLaneBlocks = 2 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
 // Where each coordinate bit lands inside the 9-bit element offset of a brick: positions of x0 x1 x2, y0 y1 y2, z0 z1 z2.
-// Default: x0 y0 | x1 y1 | z0 | x2 y2 | z1 z2 — every aligned 16-byte chunk (the unit the vector memory pipeline serves a
-// lane quad from) is a 2x2 (x,y) block of elements, every 64 bytes a 4x4 block, every 128-byte line a 4x4x2 block.
-// Measured against Z-order with every slot assignment (scripts/gpu_variants.sh).
-// -DVR_BRICK_BITS=... selects another placement (measurement aid).
+//  * 1-byte voxels (4-byte elements): x0 y0 | x1 y1 | z0 | x2 y2 | z1 z2 — every aligned 16-byte chunk (the unit the vector
+//    memory pipeline serves a lane quad from) is a 2x2 (x,y) block of elements, every 64 bytes a 4x4 block, every 128-byte
+//    line a 4x4x2 block;
+//  * 2-byte voxels (8-byte elements, served at one lane quad per step whatever the order): plain Z-order with z in the
+//    lowest, y in the middle and x in the top slot — measured 10 % faster than the order above on 1024^3 u16.
+// Both measured against the alternatives with scripts/gpu_variants.sh.  -DVR_BRICK_BITS=... /
+// -DVR_BRICK_BITS16=... select another placement (measurement aid).
 #ifndef VR_BRICK_BITS
 #define VR_BRICK_BITS 0, 2, 5, 1, 3, 6, 4, 7, 8
 #endif
-constexpr uint32_t kBrickBits[9] = { VR_BRICK_BITS };
+#ifndef VR_BRICK_BITS16
+#define VR_BRICK_BITS16 2, 5, 8, 1, 4, 7, 0, 3, 6
+#endif
+template <int BPV> struct BrickOrder;
+template <> struct BrickOrder<1> { static constexpr uint32_t bits[9] = { VR_BRICK_BITS }; };
+template <> struct BrickOrder<2> { static constexpr uint32_t bits[9] = { VR_BRICK_BITS16 }; };
 // AXIS 0 = x, 1 = y, 2 = z: spread the three low bits of a coordinate to their positions / collect them again
-template <int AXIS> __host__ __device__ inline uint32_t brick_spread(uint32_t v) {
-	return ((v & 1u) << kBrickBits[3 * AXIS]) | (((v >> 1) & 1u) << kBrickBits[3 * AXIS + 1]) | (((v >> 2) & 1u) << kBrickBits[3 * AXIS + 2]);
+template <int BPV, int AXIS> __host__ __device__ inline uint32_t brick_spread(uint32_t v) {
+	constexpr uint32_t b0 = BrickOrder<BPV>::bits[3 * AXIS], b1 = BrickOrder<BPV>::bits[3 * AXIS + 1], b2 = BrickOrder<BPV>::bits[3 * AXIS + 2];
+	return ((v & 1u) << b0) | (((v >> 1) & 1u) << b1) | (((v >> 2) & 1u) << b2);
 }
-template <int AXIS> __host__ __device__ inline uint32_t brick_collect(uint32_t local) {
-	return ((local >> kBrickBits[3 * AXIS]) & 1u) | (((local >> kBrickBits[3 * AXIS + 1]) & 1u) << 1) | (((local >> kBrickBits[3 * AXIS + 2]) & 1u) << 2);
-}
-// element offset inside a brick
-__host__ __device__ inline uint32_t brick_local(uint32_t lx, uint32_t ly, uint32_t lz) {
-	return brick_spread<0>(lx) | brick_spread<1>(ly) | brick_spread<2>(lz);
+template <int BPV, int AXIS> __host__ __device__ inline uint32_t brick_collect(uint32_t local) {
+	constexpr uint32_t b0 = BrickOrder<BPV>::bits[3 * AXIS], b1 = BrickOrder<BPV>::bits[3 * AXIS + 1], b2 = BrickOrder<BPV>::bits[3 * AXIS + 2];
+	return ((local >> b0) & 1u) | (((local >> b1) & 1u) << 1) | (((local >> b2) & 1u) << 2);
 }
 
 // Volume resident in HBM: the reference's linear layout (x fastest, then y, then z — ModelBase.h:18-22) followed by
