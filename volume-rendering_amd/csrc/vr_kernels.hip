@@ -527,10 +527,13 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		auto fetch = [&](f3 p) {
 			return kClamp ? sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, p) : sample_nearest_incube<BPV, ADDR, LAYOUT>(vol, a, lut, p);
 		};
+		// two samples ahead, like the TRILINEAR loop: (k1, p1) are the next sample, the fetch issued here is the one after it
+		float k1 = kx + step;
+		f3 p1 = march_point<SAMPLING>(origin, dir, kClamp ? k1 : __builtin_fminf(k1, ky));
 		auto step_sample = [&](const uint32_t &cur_s, uint32_t &nxt_s) {
-			const float kn = kx + step;
-			const f3 pn = march_point<SAMPLING>(origin, dir, kClamp ? kn : __builtin_fminf(kn, ky));
-			nxt_s = fetch(pn);
+			const float kn = k1, k2 = k1 + step;
+			const f3 pn = p1, p2 = march_point<SAMPLING>(origin, dir, kClamp ? k2 : __builtin_fminf(k2, ky));
+			nxt_s = fetch(p2);
 			__builtin_amdgcn_sched_barrier(0);
 			const uint32_t s = cur_s;
 			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
@@ -553,15 +556,14 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                      // CPURenderer.cpp:35-36
 			}
 			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
-			kx = kn;
-			pt = pn;
+			kx = kn; pt = pn;
+			k1 = k2; p1 = p2;
 		};
-		uint32_t sa = fetch(pt), sb = 0;
+		uint32_t sa = fetch(pt), sb = fetch(p1), sc = 0;
 		while (live != 0ull) {
-			step_sample(sa, sb);
+			step_sample(sa, sc);
 			step_sample(sb, sa);
-			step_sample(sa, sb);
-			step_sample(sb, sa);
+			step_sample(sc, sb);
 		}
 		};
 		if (a.clamp_fetch) march(std::true_type()); else march(std::false_type());
@@ -593,7 +595,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
 			uint64_t live = __builtin_amdgcn_ballot_w64(alive);
 #ifndef VR_PREFETCH_DEPTH
-#define VR_PREFETCH_DEPTH 1
+#define VR_PREFETCH_DEPTH 2
 #endif
 #if VR_PREFETCH_DEPTH == 2
 			float k1 = kx + step;                                  // k of the sample after the current one
