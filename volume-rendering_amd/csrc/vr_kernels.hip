@@ -581,10 +581,11 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		if (!alive) { kx = 0.0f; ky = 0.0f; A = mk3(0.0f, 0.0f, 0.0f); B = A; }
 		auto march = [&](auto clamp_tag) {                    // instantiated for both settings: no per-sample test of the flag
 			constexpr bool kClamp = decltype(clamp_tag)::value;
-			// Software pipeline: the loads of sample i+1 are issued before sample i is unpacked, filtered and composited, so one
-			// memory round trip overlaps one sample of arithmetic inside every wave (on top of the 8 waves per SIMD).  The
-			// body is written once (`step_sample`) and instantiated twice per iteration with the two fetch slots swapped: no
-			// register copies, one exit vote per four samples (a finished wave at worst composites three more weight-0 samples).
+			// Software pipeline: the loads of sample i+2 (VR_PREFETCH_DEPTH; i+1 with depth 1) are issued before sample i is
+			// unpacked, filtered and composited, so memory round trips overlap the arithmetic inside every wave (on top of the
+			// 8 waves per SIMD).  The body is written once (`step_sample`) and instantiated once per fetch slot and iteration
+			// with the slots rotated: no register copies, one exit vote per three samples (a finished wave at worst composites
+			// two more weight-0 samples).
 			auto issue = [&](float k) {
 				if (!kClamp) k = __builtin_fminf(k, ky);
 				return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
