@@ -174,10 +174,16 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 			}
 		}
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
+#ifdef VR_EXP_ONE_LOAD64                             // measurement only (wrong images): ONE 8-byte gather per sample
+			{
+				const uint2 both = *(const uint2 *) ((uintptr_t) q0 & ~(uintptr_t) 7);
+				f.w0 = both.x; f.w1 = both.y;
+			}
+#elif defined(VR_EXP_ONE_LOAD)                       // measurement only (wrong images): what does the second load cost?
 			f.w0 = *(const uint32_t *) q0;
-#ifdef VR_EXP_ONE_LOAD                               // measurement only (wrong images): what does the second load cost?
 			f.w1 = f.w0;
 #else
+			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
 #endif
 #ifdef VR_EXP_DUP_LOADS
