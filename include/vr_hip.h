@@ -55,7 +55,8 @@ typedef enum vr_layout {
 	VR_LAYOUT_BRICKED = 1     /* default: "quad bricks" — every element packs the 2x2 (x,y) voxel neighbourhood of a slice into
 	                             one aligned word, stored in 8x8x8-element bricks: a trilinear sample is two aligned loads
 	                             and the cache-line footprint no longer depends on the view direction
-	                             (4x the voxel bytes in HBM; volume-rendering_amd/csrc/vr_device.h) */
+	                             (4x the voxel bytes in HBM per copy, up to three copies for 1-byte voxels — vr_hip_set_brick_plane;
+	                             volume-rendering_amd/csrc/vr_device.h) */
 } vr_layout;
 
 /* struct View, ViewBase.h:14-21 (dims widened to 32 bit, bool -> uint32) */
@@ -130,6 +131,12 @@ int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
  * 2048), 2 = address tables with 64-bit z offsets (dims up to 2048), 0 = automatic; + 4 = clamp the fetch coordinates of
  * every TRILINEAR sample, which only views very far from the volume need.  Images are identical either way. */
 int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
+
+/* Which of the up to three brick copies the TRILINEAR fetch reads — they differ in the plane, (x,y) / (x,z) / (y,z), that the
+ * 16-byte chunks of the brick order cover (volume-rendering_amd/csrc/vr_device.h): -1 = per view, the plane perpendicular to
+ * the view's dominant axis (default); 0, 1, 2 = always that plane (where the copy exists: 1-byte voxels, edges up to 1024,
+ * else (x,y)).  Speed only; testing and tuning aid.  No reference counterpart. */
+int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
 /* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
  * lane_map -1 = chosen per frame from the view (default); 0 = 4 pixels along screen x, 1 = along screen y, 2 = 2x2-pixel

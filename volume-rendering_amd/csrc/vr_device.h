@@ -36,6 +36,7 @@ struct RayKernelArgs {
 	uint32_t clamp_fetch;              // 1: clamp the fetch coordinates of every sample (views whose fp32 coordinates may leave (-1, N))
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
+	uint32_t brick_plane;              // chunk plane of the brick copy handed to the kernel (kPlaneXY ...)
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
@@ -57,30 +58,30 @@ enum : uint32_t { kLaneRows = 0, kLaneColumns = 1, kLaneBlocks = 2 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
 // Where each coordinate bit lands inside the 9-bit element offset of a brick: positions of x0 x1 x2, y0 y1 y2, z0 z1 z2.
-//  * 1-byte voxels (4-byte elements): x0 y0 | x1 y1 | z0 | x2 y2 | z1 z2 — every aligned 16-byte chunk (the unit the vector
-//    memory pipeline serves a lane quad from) is a 2x2 (x,y) block of elements, every 64 bytes a 4x4 block, every 128-byte
-//    line a 4x4x2 block;
+//  * 1-byte voxels (4-byte elements): a0 b0 | a1 b1 | c0 | a2 b2 | c1 c2 for a "chunk plane" (a,b) — every aligned 16-byte
+//    chunk (the unit the vector memory pipeline serves a lane quad from) is a 2x2 (a,b) block of elements, every 64 bytes a
+//    4x4 block, every 128-byte line a 4x4x2 block.  Up to three copies exist, one per chunk plane (x,y) / (x,z) / (y,z);
+//    the host picks the plane perpendicular to the view's dominant axis (vr_hip_api.cpp), NEAREST always reads (x,y);
 //  * 2-byte voxels (8-byte elements, served at one lane quad per step whatever the order): plain Z-order with z in the
 //    lowest, y in the middle and x in the top slot — measured 10 % faster than the order above on 1024^3 u16.
-// Both measured against the alternatives with scripts/gpu_variants.sh.  -DVR_BRICK_BITS=... /
-// -DVR_BRICK_BITS16=... select another placement (measurement aid).
-#ifndef VR_BRICK_BITS
-#define VR_BRICK_BITS 0, 2, 5, 1, 3, 6, 4, 7, 8
-#endif
-#ifndef VR_BRICK_BITS16
-#define VR_BRICK_BITS16 2, 5, 8, 1, 4, 7, 0, 3, 6
-#endif
-template <int BPV> struct BrickOrder;
-template <> struct BrickOrder<1> { static constexpr uint32_t bits[9] = { VR_BRICK_BITS }; };
-template <> struct BrickOrder<2> { static constexpr uint32_t bits[9] = { VR_BRICK_BITS16 }; };
-// AXIS 0 = x, 1 = y, 2 = z: spread the three low bits of a coordinate to their positions / collect them again
-template <int BPV, int AXIS> __host__ __device__ inline uint32_t brick_spread(uint32_t v) {
-	constexpr uint32_t b0 = BrickOrder<BPV>::bits[3 * AXIS], b1 = BrickOrder<BPV>::bits[3 * AXIS + 1], b2 = BrickOrder<BPV>::bits[3 * AXIS + 2];
-	return ((v & 1u) << b0) | (((v >> 1) & 1u) << b1) | (((v >> 2) & 1u) << b2);
+// All measured against the alternatives with scripts/gpu_variants.sh / gpu_orders.sh.
+enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
+// bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
+__host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
+	constexpr uint8_t table[4][9] = {
+		{ 0, 2, 5, 1, 3, 6, 4, 7, 8 },      // chunk plane (x,y)
+		{ 0, 2, 5, 4, 7, 8, 1, 3, 6 },      // chunk plane (x,z)
+		{ 4, 7, 8, 0, 2, 5, 1, 3, 6 },      // chunk plane (y,z)
+		{ 2, 5, 8, 1, 4, 7, 0, 3, 6 },      // 2-byte voxels: Z-order
+	};
+	return table[bytes_per_voxel == 2 ? 3u : plane][3 * axis + k];
 }
-template <int BPV, int AXIS> __host__ __device__ inline uint32_t brick_collect(uint32_t local) {
-	constexpr uint32_t b0 = BrickOrder<BPV>::bits[3 * AXIS], b1 = BrickOrder<BPV>::bits[3 * AXIS + 1], b2 = BrickOrder<BPV>::bits[3 * AXIS + 2];
-	return ((local >> b0) & 1u) | (((local >> b1) & 1u) << 1) | (((local >> b2) & 1u) << 2);
+// spread the three low bits of a coordinate to their positions / collect them again
+__host__ __device__ inline uint32_t brick_spread(uint32_t bpv, uint32_t plane, uint32_t axis, uint32_t v) {
+	return ((v & 1u) << brick_bit(bpv, plane, axis, 0)) | (((v >> 1) & 1u) << brick_bit(bpv, plane, axis, 1)) | (((v >> 2) & 1u) << brick_bit(bpv, plane, axis, 2));
+}
+__host__ __device__ inline uint32_t brick_collect(uint32_t bpv, uint32_t plane, uint32_t axis, uint32_t local) {
+	return ((local >> brick_bit(bpv, plane, axis, 0)) & 1u) | (((local >> brick_bit(bpv, plane, axis, 1)) & 1u) << 1) | (((local >> brick_bit(bpv, plane, axis, 2)) & 1u) << 2);
 }
 
 // Volume resident in HBM: the reference's linear layout (x fastest, then y, then z — ModelBase.h:18-22) followed by
@@ -89,7 +90,7 @@ template <int BPV, int AXIS> __host__ __device__ inline uint32_t brick_collect(u
 inline uint64_t volume_tail_slack(uint32_t dim_x, uint32_t dim_y) { return (uint64_t) dim_x * dim_y + dim_x + 2; }
 
 // linear -> quad-brick copy
-hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y,
+hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per_voxel, uint32_t plane, uint32_t dim_x, uint32_t dim_y,
                            uint32_t dim_z, hipStream_t stream);
 // number of quad elements (each 4 * bytes_per_voxel bytes)
 inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {

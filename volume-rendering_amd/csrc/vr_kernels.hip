@@ -156,9 +156,9 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		if (ADDR == kAddrWide) {
 			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
 			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
-			const uint32_t lxy = brick_spread<BPV, 0>(ix & 7u) | brick_spread<BPV, 1>(iy & 7u);
-			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread<BPV, 2>(iz & 7u))) * kElem;
-			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread<BPV, 2>(iz1 & 7u))) * kElem;
+			const uint32_t lxy = brick_spread(BPV, a.brick_plane, 0, ix & 7u) | brick_spread(BPV, a.brick_plane, 1, iy & 7u);
+			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread(BPV, a.brick_plane, 2, iz & 7u))) * kElem;
+			q1 = (const uint8_t *) vol + (((iz1 >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread(BPV, a.brick_plane, 2, iz1 & 7u))) * kElem;
 		} else {
 			// per-axis byte-offset tables in LDS (LutCfg): brick base + Morton-dilated in-brick offset, split by axis
 			typedef LutCfg<ADDR> L;
@@ -372,8 +372,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t i = t; i < nz; i += kThreads) {
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
-				const uint64_t z0 = ((i >> 3) * slab + brick_spread<BPV, 2>(i & 7u)) * elem;
-				const uint64_t z1 = ((j >> 3) * slab + brick_spread<BPV, 2>(j & 7u)) * elem;
+				const uint64_t z0 = ((i >> 3) * slab + brick_spread(BPV, a.brick_plane, 2, i & 7u)) * elem;
+				const uint64_t z1 = ((j >> 3) * slab + brick_spread(BPV, a.brick_plane, 2, j & 7u)) * elem;
 				if (ADDR == kAddr32) {
 					lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) z1;
 				} else {
@@ -381,8 +381,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					lut[4 * i + 2] = (uint32_t) z1; lut[4 * i + 3] = (uint32_t) (z1 >> 32);
 				}
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + brick_spread<BPV, 0>(i & 7u)) * elem;
-			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + brick_spread<BPV, 1>(i & 7u)) * elem;
+			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + brick_spread(BPV, a.brick_plane, 0, i & 7u)) * elem;
+			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + brick_spread(BPV, a.brick_plane, 1, i & 7u)) * elem;
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -744,7 +744,7 @@ hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const voi
 
 template <int BPV>
 __global__ __launch_bounds__(256)
-void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t plane, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                      uint32_t nbx, uint32_t nby, uint32_t nbz) {
 	typedef typename VoxelT<BPV>::type V;
 	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
@@ -753,7 +753,7 @@ void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint3
 		const uint64_t brick = o / kBrickPitch;
 		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
 		// undo the Morton order
-		const uint32_t lz = brick_collect<BPV, 2>(local), lx = brick_collect<BPV, 0>(local), ly = brick_collect<BPV, 1>(local);
+		const uint32_t lz = brick_collect(BPV, plane, 2, local), lx = brick_collect(BPV, plane, 0, local), ly = brick_collect(BPV, plane, 1, local);
 		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
 		const uint32_t by = br / nbx, bx = br - by * nbx;
 		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
@@ -771,12 +771,12 @@ void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint3
 	}
 }
 
-hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint32_t plane, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                            hipStream_t stream) {
 	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge,
 	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
-	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	return hipGetLastError();
 }
 
