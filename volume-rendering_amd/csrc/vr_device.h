@@ -64,7 +64,7 @@ constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 //    the host picks the plane perpendicular to the view's dominant axis (vr_hip_api.cpp), NEAREST always reads (x,y);
 //  * 2-byte voxels (8-byte elements, served at one lane quad per step whatever the order): plain Z-order with z in the
 //    lowest, y in the middle and x in the top slot — measured 10 % faster than the order above on 1024^3 u16.
-// All measured against the alternatives with scripts/gpu_variants.sh / gpu_orders.sh.
+// All measured against the alternatives with scripts/gpu_variants.sh / gpu_planes.sh.
 enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
