@@ -43,6 +43,7 @@ struct __attribute__((aligned(16))) LdsTables {
 	f4 tf[VR_TF_SIZE + 1];         // premultiplied TF; entry 128 duplicates 127 (clamp addressing of the filtered lookup)
 	f4 dtf[VR_TF_SIZE + 1];        // dtf[i] = tf[i+1] - tf[i] (same fp32 subtraction the lerp would do per sample)
 	uint32_t esl[VR_ESL_VOLUME_SIZE];
+	float unit[256];               // NEAREST, 1-byte voxels: unit[s] = (float) s / 255.0f, the quotient Raycaster::shade forms twice per shaded sample
 };
 
 // How voxel addresses are formed (template parameter ADDR):
@@ -394,6 +395,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			lds.dtf[t] = d;
 		}
 		for (uint32_t i = t; i < VR_ESL_VOLUME_SIZE; i += kThreads) lds.esl[i] = esl_g[i];
+		if (SAMPLING == VR_SAMPLE_NEAREST && BPV == 1 && t < 256u) lds.unit[t] = (float) t / 255.0f;   // the same IEEE division, once
 	}
 	__syncthreads();
 
@@ -552,8 +554,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
-					float sl = (float) sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps) / raw;
-					const float diffuse = select_lanes(shaded, (sl - (float) s / raw) * kd);     // x + 0 == x: unshaded lanes unchanged
+					const uint32_t s_l = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps);
+					const float sl = BPV == 1 ? lds.unit[s_l] : (float) s_l / raw;                  // RaycasterBase.h:93-96
+					const float sc = BPV == 1 ? lds.unit[s] : (float) s / raw;
+					const float diffuse = select_lanes(shaded, (sl - sc) * kd);                   // x + 0 == x: unshaded lanes unchanged
 					cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
 				}
 				const float t = select_lanes(live, 1 - acc.w);                                    // CPURenderer.cpp:34
