@@ -4,30 +4,33 @@ synthetic "shell" 1024^3 u8 volume (1 GiB, resident in HBM) rendered at 2048 x 2
 through the reference's 8 benchmark views (2 projections x 4 poses at distance 2, VolR.cpp:225-253).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
 
-A step = one whole frame: every rank (one process per GPU) renders its interleaved 16-row bands of the frame with the
-hand-written gfx950 kernel (replicated volume), then the RGBA8 bands are gathered on rank 0 over RCCL (xGMI).  The work
-per frame is fixed as N grows => "scaling": "strong".  Default mode is the reference's "no optims" configuration
-(VolR.cpp:283-287: empty-space leaping off, early-ray-termination threshold 1.0, light on) — the full march, the only
-mode whose algorithmic bytes are view independent (260 B/ray) — in TRILINEAR sampling (GPURenderer4
-semantics, the heavier mode).  The reference's default mode (ESL + ERT) and NEAREST sampling are timed as extras.
+With N > 1 and no torch.distributed environment the script starts N ranks of itself (one per GPU) through
+`python -m torch.distributed.run` and relays rank 0's JSON line; launched under torch.distributed.run directly
+(RANK / LOCAL_RANK / WORLD_SIZE set) it runs as one of the ranks.  The parent process never touches a GPU.
+
+A step = one whole frame: every rank renders its interleaved bands of the frame with the hand-written gfx950 kernel
+(replicated volume), then the RGBA8 bands are gathered on rank 0 over RCCL (xGMI).  The work per frame is fixed as N
+grows => "scaling": "strong".  Default mode is the reference's "no optims" configuration (VolR.cpp:283-287:
+empty-space leaping off, early-ray-termination threshold 1.0, light on) — the full march, the only mode whose
+algorithmic bytes are view independent (260 B/ray) — in TRILINEAR sampling (GPURenderer4 semantics, the
+heavier mode).  The reference-pinned NEAREST sampling, the reference's default mode (ESL + ERT) and its ERT-only mode
+(VolR.cpp:288-290) are timed as extras, the latter two with a roofline over the bytes their sample sets touch.
 
 Rank 0 prints ONE JSON line.  With --gpus 1 it also times the reference's own CPURenderer (oracle/_ref, built from the
-reference sources in the build container) on a bounded sample of the same workload on one host core.
+reference sources in the build container) on a bounded sample of the same workload on one host core, and the OpenMP
+leg of the CPU restatement on all host cores.
+
+--dry-run (CPU, gloo): no rendering — every rank fills its bands with a row pattern and the launcher / rendezvous /
+band split / pipelined gather / JSON plumbing run exactly as in the real thing (tests/test_bench_launcher.py).
 """
 import argparse
-import ctypes as C
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,21 +45,77 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--volume", type=int, default=1024, help="cube edge of the synthetic shell volume")
     ap.add_argument("--viewport", type=int, default=2048)
-    ap.add_argument("--mode", choices=("nooptims", "default"), default="nooptims")
+    ap.add_argument("--mode", choices=("nooptims", "default", "ertonly"), default="nooptims")
     ap.add_argument("--sampling", choices=("trilinear", "nearest"), default="trilinear")
-    ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = 16, or the whole frame at N=1)")
+    ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--cpu-band-rows", type=int, default=96, help="rows per view of the CPU-baseline sample")
+    ap.add_argument("--cpu-band-rows", type=int, default=96, help="rows per view of the 1-core CPU-baseline sample")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the multi-rank plumbing, nothing is rendered")
+    ap.add_argument("--force-launcher", action="store_true", help="start the ranks as child processes even for --gpus 1")
     return ap.parse_args()
 
 
+# ---- launcher ------------------------------------------------------------------------------------------------------------
+
+def launch_ranks(a):
+    """Parent of an N-rank run: starts `python -m torch.distributed.run ... bench.py <same flags>` and relays rank 0's
+    JSON line and the exit code.  Nothing in this process initialises HIP."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [x for x in sys.argv[1:] if x != "--force-launcher"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 3
+    return rc
+
+
+# ---- CPU baselines (rank 0, N = 1 only) ----------------------------------------------------------------------------------
+
 def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
-    """The reference's CPURenderer::render_volume (compiled from the reference sources into oracle/_ref) on one host core,
-    on a bounded sample: one band of `band_rows` rows per benchmark view (8 bands spread over the frame height), same
-    volume / TF / mode; NEAREST sampling because that is what the reference's CPU renderer does."""
+    """The reference's CPURenderer::render_volume (compiled from the reference sources into oracle/_ref) on ONE host core
+    — the reference's loop is serial, CPURenderer.cpp:48-51 — on a bounded sample: one band of `band_rows` rows per
+    benchmark view (8 bands spread over the frame height), same volume / TF / mode; NEAREST sampling because that is what
+    the reference's CPU renderer does.  Beside it, `all_cores`: the OpenMP leg of the CPU restatement (oracle/vr_oracle.c,
+    rows in parallel) on every host core, on a sample four times as large."""
+    import ctypes as C
+    import numpy as np
+
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libvolr_ref.so")
     vox = renderer.download_volume()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import Oracle                       # cpu_baseline leg: the oracle only as the thing timed beside us
+    oracle = Oracle()
+
+    def port_leg(rows, threads):
+        rays, secs = 0, 0.0
+        for i, v in enumerate(views):
+            p = scene.frame_params(v, vr.SAMPLE_NEAREST)
+            nb = height // rows
+            p.out_rows, p.band_rows, p.band_stride = rows, rows, nb
+            p.band_first = min(nb - 1, int((i + 0.5) * nb / len(views)))
+            t0 = time.perf_counter()
+            oracle.render(p, vox, scene.tf, scene.esl, threads=threads)
+            secs += time.perf_counter() - t0
+            rays += width * rows
+        return rays, secs
+
     if os.path.exists(ref_so):
         L = C.CDLL(ref_so)
         devnull = os.open(os.devnull, os.O_WRONLY)      # the reference's Logger prints to stdout: keep our JSON line alone
@@ -95,97 +154,112 @@ def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
             os.close(saved)
         kind = "reference"
     else:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from helpers import Oracle                       # cpu_baseline leg: the oracle only as the thing timed beside us
-        oracle = Oracle()
-        rays, secs = 0, 0.0
-        for i, v in enumerate(views):
-            p = scene.frame_params(v, vr.SAMPLE_NEAREST)
-            nb = height // band_rows
-            p.out_rows, p.band_rows, p.band_stride = band_rows, band_rows, nb
-            p.band_first = min(nb - 1, int((i + 0.5) * nb / len(views)))
-            t0 = time.perf_counter()
-            oracle.render(p, vox, scene.tf, scene.esl, threads=1)
-            secs += time.perf_counter() - t0
-            rays += width * band_rows
+        rays, secs = port_leg(band_rows, 1)
         kind = "port"
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    all_rows = min(height // len(views), 4 * band_rows)
+    a_rays, a_secs = port_leg(all_rows, cores)
     return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind,
             "sample": f"{len(views)} bands x {band_rows} rows (one per benchmark view) of the {width}x{height} frame = "
                       f"{rays} rays, {secs:.1f} s; NEAREST sampling (CPURenderer.cpp semantics), same volume/TF/mode",
-            "ms_per_frame_extrapolated": round(secs / rays * width * height * 1e3, 1)}
+            "ms_per_frame_extrapolated": round(secs / rays * width * height * 1e3, 1),
+            "all_cores": {"value": round(a_rays / a_secs / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                          "sample": f"OpenMP over rows (oracle/vr_oracle.c), {len(views)} bands x {all_rows} rows = {a_rays} rays, "
+                                    f"{a_secs:.1f} s", "ms_per_frame_extrapolated": round(a_secs / a_rays * width * height * 1e3, 1)}}
 
 
-def recorded_traffic(key):
-    """HBM bytes per launch from the PMC pass of the SAME command (profiles/r01_traffic.json, written by
-    scripts/profile_bench.sh from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).
-    None when no matching profile has been recorded — PMC counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def recorded(path, key):
     try:
-        with open(path) as f:
-            rec = json.load(f)
-        return rec.get(key)
+        with open(os.path.join(ROOT, path)) as f:
+            return json.load(f).get(key)
     except (OSError, ValueError):
         return None
 
 
-def main():
+# ---- one rank ------------------------------------------------------------------------------------------------------------
+
+def run_rank(a):
     # Rank 0 must print exactly ONE line on stdout.  Native libraries in this process write there too (RCCL prints a version
     # banner on init, the reference's Logger prints on init), so file descriptor 1 is pointed at stderr for the whole run
     # and the JSON line goes to the saved descriptor at the very end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    a = parse()
+    import importlib
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    distributed = world > 1 or "RANK" in os.environ            # under torch.distributed.run even N=1 goes through RCCL
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)      # "nccl" IS RCCL on ROCm
-
-    vr = importlib.import_module("volume-rendering_amd")
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    distributed = world > 1 or "RANK" in os.environ            # under torch.distributed.run even N=1 goes through the collective
     dmod = importlib.import_module("volume-rendering_amd.distributed")
-    r = vr.HipRenderer(local_rank)
     n, W, H = a.volume, a.viewport, a.viewport
-
-    # -- scene: volume generated in HBM, ESL min/max by the streaming reduction, TF/ESL/ray_step by the host mirror
-    r.generate_volume("shell", n, seed=1)
-    minmax, _, _, minmax_ms = r.volume_minmax()
-    _, minmax_ms = r.volume_minmax()[0], r.volume_minmax()[3]       # second run: warm clocks
-    scene = vr.Scene().set_volume(dims=(n, n, n), minmax=minmax)
-    if a.mode == "nooptims":
-        scene.set_modes(esl=False, ray_threshold=1.0)               # VolR.cpp:285-286
-    r.set_transfer_fn(scene.tf, scene.esl)
-    sampling = vr.SAMPLE_TRILINEAR if a.sampling == "trilinear" else vr.SAMPLE_NEAREST
-    views = [vr.benchmark_view(W, H, i) for i in range(8)]
-
     band_rows = a.band_rows or dmod.default_band_rows(H, world)
     split = dmod.FrameSplit(W, H, world, rank, band_rows)
-    # two frames in flight: frame i+1 is rendered while the bands of frame i travel to rank 0 on RCCL's stream
+
+    if a.dry_run:
+        device = torch.device("cpu")
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        vr = r = scene = None
+        views = list(range(8))
+        params = [None] * 8
+        rows = torch.arange(split.local_rows)
+        frame_rows = ((rows // band_rows) * world + rank) * band_rows + rows % band_rows      # frame row of every local row
+        stream_ctx, stream = None, None
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        if distributed:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)      # "nccl" IS RCCL on ROCm
+        vr = importlib.import_module("volume-rendering_amd")
+        r = vr.HipRenderer(local_rank)
+        # -- scene: volume generated in HBM, ESL min/max by the streaming reduction, TF/ESL/ray_step by the host mirror
+        r.generate_volume("shell", n, seed=1)
+        minmax = r.volume_minmax()[0]
+        minmax_ms = r.volume_minmax()[3]                        # second run: warm clocks
+        scene = vr.Scene().set_volume(dims=(n, n, n), minmax=minmax)
+        set_mode(scene, a.mode)
+        r.set_transfer_fn(scene.tf, scene.esl)
+        sampling = vr.SAMPLE_TRILINEAR if a.sampling == "trilinear" else vr.SAMPLE_NEAREST
+        views = [vr.benchmark_view(W, H, i) for i in range(8)]
+        params = [split.apply(scene.frame_params(v, sampling)) for v in views]
+        # Rendering, the RCCL gather and the de-interleave copy are all ordered through ONE stream torch knows about: the
+        # kernel is launched on it (the C ABI takes the raw hipStream_t), dist.gather() makes RCCL's stream wait for it, and
+        # work.wait() makes it wait for RCCL before the buffer pair is rendered into again.
+        render_stream = torch.cuda.Stream(device)
+        stream_ctx, stream = torch.cuda.stream(render_stream), render_stream.cuda_stream
+
+    # two frames in flight: frame i+1 is rendered while the bands of frame i travel to rank 0 on the backend's stream
     local = [split.local_buffer(device) for _ in range(2)]
     staging = [split.staging_buffer(device) if (rank == 0 and distributed) else None for _ in range(2)]
     pending = [None, None]
-    params = [split.apply(scene.frame_params(v, sampling)) for v in views]
-    stream = torch.cuda.current_stream().cuda_stream
-
     # the assembled frame (what a display or an encoder would consume) lives on rank 0
-    final = torch.empty((H, W, 4), dtype=torch.uint8, device=device) if (rank == 0 and distributed) else None
+    final = torch.empty((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+
+    def render(i, slot):
+        if a.dry_run:
+            local[slot].copy_(((frame_rows + i) % 251).to(torch.uint8).view(-1, 1, 1).expand(-1, W, 4))
+        else:
+            r.render_volume_device(params[i % 8], local[slot].data_ptr(), stream)
 
     def retire(slot):
-        """Frame in `slot` has been gathered: order the current stream after the transfer and de-interleave the bands
+        """Frame in `slot` has been gathered: order the render stream after the transfer and de-interleave the bands
         into the final frame (one strided copy kernel on rank 0)."""
         if pending[slot] is None:
             return
         work, finish = pending[slot]
-        work.wait()
+        if work is not None:
+            work.wait()
         frame = finish()
         if final is not None and frame is not None:
             final.copy_(frame)
@@ -194,29 +268,55 @@ def main():
     def step(i):
         slot = i & 1
         retire(slot)                                # the buffer pair of frame i-2 is free again
-        r.render_volume_device(params[i % 8], local[slot].data_ptr(), stream)
-        work, finish = split.gather_async(local[slot], staging[slot])
-        if work is not None:
-            pending[slot] = (work, finish)
+        render(i, slot)
+        pending[slot] = split.gather_async(local[slot], staging[slot])
 
     def fence():
         retire(0)
         retire(1)
         if distributed:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+            dist.barrier(device_ids=None if a.dry_run else [local_rank])
+        if not a.dry_run:
+            torch.cuda.synchronize()
 
-    for i in range(a.warmup):
+    def timed_region():
+        for i in range(a.warmup):
+            step(i)
+        fence()
+        if r is not None:
+            r.timing_reset()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        fence()
+        return time.perf_counter() - t0
+
+    def check_frame():
+        """One more frame through the N-rank path, compared on rank 0 with rank 0's own whole-frame render of that view."""
+        i = a.warmup + a.steps
         step(i)
-    fence()
-    r.timing_reset()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    tm = r.timing()
-    per_rank_kernel_ms = [tm.kernel_ms_sum / max(1, tm.launches)]
+        fence()
+        if rank != 0:
+            return None
+        if a.dry_run:
+            want = ((torch.arange(H) + i) % 251).to(torch.uint8).view(-1, 1, 1).expand(-1, W, 4)
+            return "ok" if torch.equal(final, want) else "MISMATCH"
+        whole = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
+        r.render_volume_device(vr.whole_frame(scene.frame_params(views[i % 8], sampling)), whole.data_ptr(), stream)
+        torch.cuda.current_stream().synchronize()
+        return "ok" if torch.equal(final, whole) else "MISMATCH"
+
+    if stream_ctx is not None:
+        with stream_ctx:
+            elapsed = timed_region()
+            tm = r.timing()
+            frame_check = check_frame()
+    else:
+        elapsed = timed_region()
+        tm = None
+        frame_check = check_frame()
+
+    per_rank_kernel_ms = [tm.kernel_ms_sum / max(1, tm.launches)] if tm is not None else [0.0]
     if distributed:
         t = torch.tensor([elapsed, per_rank_kernel_ms[0]], dtype=torch.float64, device=device)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -226,69 +326,122 @@ def main():
     else:
         kernel_ms = per_rank_kernel_ms[0]
 
+    rc = 0
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         mrays = W * H / (elapsed / a.steps) / 1e6
-        # ALGORITHMIC bytes per launch: compulsory HBM traffic = every voxel once + the RGBA8 framebuffer,
-        # 260 B/ray at 1024^3 @ 2048^2 in the full march; one launch covers 1/world of the frame and of the voxel rows.
-        alg_bytes = (n ** 3 * 1 + 4 * W * H) / world
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        partition = (f"{world} rank(s) x interleaved {band_rows}-row bands, "
+                     f"{'gloo' if a.dry_run else 'RCCL'} gather to rank 0, 2 frames in flight") if distributed else "single GPU, whole frame"
         out = {
             "metric": "Mrays/s (W*H / t_frame), 1024^3 volume @ 2048^2 viewport", "value": round(mrays, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"shell {n}^3 u8 (seed 1) @ {W}x{H}, reference's 8 benchmark views cycled, "
-                                   f"mode={a.mode} ({'ESL off, threshold 1.0' if a.mode == 'nooptims' else 'ESL on, threshold 0.95'}, "
-                                   f"light_kd 0.6), sampling={a.sampling}",
-                       "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": 1, "ray_step": float(scene.params.ray_step),
-                       "partition": f"{world} rank(s) x interleaved {band_rows}-row bands, RCCL gather to rank 0, 2 frames in flight" if world > 1 else "single GPU, whole frame"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": recorded_traffic(f"{a.mode}_{a.sampling}_{n}_{W}_n{world}"), "kernel": "vr::raymarch_kernel",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
-                         "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
-                         "note": "full march is gather/VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling')"},
-            "minmax_feeder": {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
-                              "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),
-                              "frac_of_hbm_peak": round(n ** 3 / (minmax_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "frame_check": frame_check,
         }
-        if not a.no_extras and world == 1:
-            extras = {}
-            for label, mode, samp in (("nooptims_nearest", "nooptims", vr.SAMPLE_NEAREST),
-                                      ("default_trilinear", "default", vr.SAMPLE_TRILINEAR),
-                                      ("default_nearest", "default", vr.SAMPLE_NEAREST)):
-                if mode == "nooptims":
-                    scene.set_modes(esl=False, ray_threshold=1.0)
-                else:
-                    scene.set_modes(esl=True, ray_threshold=0.95)
-                ps = [split.apply(scene.frame_params(v, samp)) for v in views]
-                for p in ps:
-                    r.render_volume_device(p, local[0].data_ptr(), stream)
-                torch.cuda.synchronize()
-                r.timing_reset()
-                t1 = time.perf_counter()
-                for p in ps:
-                    r.render_volume_device(p, local[0].data_ptr(), stream)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 8
-                extras[label] = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_per_s": round(W * H / dt / 1e6, 1)}
-            out["extras"] = extras
-            if a.mode == "nooptims":
-                scene.set_modes(esl=False, ray_threshold=1.0)
-            else:
-                scene.set_modes(esl=True, ray_threshold=0.95)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
+        if frame_check != "ok":
+            rc = 4
+        if a.dry_run:
+            out.update({"dry_run": True, "value": 0.0,
+                        "config": {"workload": "DRY RUN: no rendering, row-pattern bands through the real split / gather / launcher code",
+                                   "viewport": [W, H], "partition": partition}})
         else:
-            out["cpu_baseline"] = None
+            mode_txt = {"nooptims": "ESL off, threshold 1.0", "default": "ESL on, threshold 0.95", "ertonly": "ESL off, threshold 0.95"}[a.mode]
+            out["config"] = {"workload": f"shell {n}^3 u8 (seed 1) @ {W}x{H}, reference's 8 benchmark views cycled, "
+                                         f"mode={a.mode} ({mode_txt}, light_kd 0.6), sampling={a.sampling}",
+                             "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": 1, "ray_step": float(scene.params.ray_step),
+                             "partition": partition}
+            # ALGORITHMIC bytes per launch: compulsory HBM traffic = every voxel once + the RGBA8 framebuffer,
+            # 260 B/ray at 1024^3 @ 2048^2 in the full march; one launch covers 1/world of the frame and of the voxel rows.
+            key = f"{a.mode}_{a.sampling}_{n}_{W}"
+            if a.mode == "nooptims":
+                alg_bytes = (n ** 3 * 1 + 4 * W * H) / world
+            else:
+                touched = recorded("tests/golden/vtouched.json", key)
+                alg_bytes = ((touched["mean_bytes"] if touched else n ** 3) + 4 * W * H) / world
+            achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+            traffic = recorded("profiles/r02_traffic.json", f"{key}_n{world}") or {}
+            out["roofline"] = {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": traffic.get("bytes_per_launch"), "traffic_commit": traffic.get("commit"),
+                "traffic_kernel_ms": traffic.get("kernel_ms"),
+                "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
+                "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
+                "note": "full march is gather/VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling')"}
+            out["minmax_feeder"] = {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
+                                    "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),
+                                    "frac_of_hbm_peak": round(n ** 3 / (minmax_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if not a.no_extras and world == 1:
+                out["extras"] = extras(vr, r, scene, views, split, local[0], stream, render_stream, n, W, H)
+                set_mode(scene, a.mode)
+            if world == 1 and not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
+            else:
+                out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=None if a.dry_run else [local_rank])
         dist.destroy_process_group()
-    r.close()
+    if r is not None:
+        r.close()
+    return rc
+
+
+def set_mode(scene, mode):
+    """The three configurations of the reference's optimisation benchmark, VolR.cpp:283-294."""
+    if mode == "nooptims":
+        scene.set_modes(esl=False, ray_threshold=1.0)
+    elif mode == "ertonly":
+        scene.set_modes(esl=False, ray_threshold=0.95)
+    else:
+        scene.set_modes(esl=True, ray_threshold=0.95)
+
+
+def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H):
+    """Same volume and views in the other sampling mode and in the reference's two optimised configurations; for those the
+    roofline uses V_touched, the bytes of the distinct 128-byte voxel lines the frame's sample set reads, counted by the
+    CPU restatement in the build container (oracle/gen_vtouched.py -> tests/golden/vtouched.json)."""
+    res = {}
+    for label, mode, samp in (("nooptims_nearest", "nooptims", vr.SAMPLE_NEAREST),
+                              ("default_trilinear", "default", vr.SAMPLE_TRILINEAR),
+                              ("default_nearest", "default", vr.SAMPLE_NEAREST),
+                              ("ertonly_trilinear", "ertonly", vr.SAMPLE_TRILINEAR),
+                              ("ertonly_nearest", "ertonly", vr.SAMPLE_NEAREST)):
+        set_mode(scene, mode)
+        ps = [split.apply(scene.frame_params(v, samp)) for v in views]
+        for p in ps:
+            r.render_volume_device(p, buf.data_ptr(), stream)
+        render_stream.synchronize()
+        r.timing_reset()
+        t1 = time.perf_counter()
+        for p in ps:
+            r.render_volume_device(p, buf.data_ptr(), stream)
+        render_stream.synchronize()
+        dt = (time.perf_counter() - t1) / 8
+        tm = r.timing()
+        kernel_ms = tm.kernel_ms_sum / max(1, tm.launches)
+        e = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_per_s": round(W * H / dt / 1e6, 1), "kernel_ms": round(kernel_ms, 4)}
+        if mode == "nooptims":
+            alg = n ** 3 + 4 * W * H
+        else:
+            touched = recorded("tests/golden/vtouched.json", f"{mode}_{'trilinear' if samp == vr.SAMPLE_TRILINEAR else 'nearest'}_{n}_{W}")
+            alg = (touched["mean_bytes"] + 4 * W * H) if touched else None
+        if alg:
+            ach = alg / (kernel_ms * 1e-3) / 1e9
+            e["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5)}
+        res[label] = e
+    return res
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.force_launcher):
+        return launch_ranks(a)
+    return run_rank(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -21,8 +21,9 @@ def load_volume(gpu, golden, name):
 
 
 def test_native_library_is_the_one_loaded(vr, gpu):
+    import os
     with open("/proc/self/maps") as f:
-        assert "libvr_hip.so" in f.read()
+        assert os.path.basename(vr.library_path()) in f.read()      # in-tree libvr_hip.so (or the VR_HIP_LIB build under A/B)
     name, cus, mem = gpu.device_info()
     assert "gfx950" in name and cus == 256, (name, cus)
 
@@ -205,10 +206,16 @@ def test_device_buffer_path_with_torch_stream(vr, gpu, golden):
     gpu.set_window_buffer(256, 256)
     case = [c for c in golden.cases(True) if c["label"] == "bench256_view5_default"][0]
     p = golden.params(case, vr.SAMPLE_NEAREST)
-    dev = torch.full((256, 256, 4), 77, dtype=torch.uint8, device="cuda:0")     # the kernel must overwrite every byte
-    gpu.render_volume_device(p, dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert np.array_equal(dev.cpu().numpy(), golden.frame(case))
+    # A stream torch owns (non-zero handle): the fill, the kernel and the copy back are ordered on it.  Handle 0 / NULL would
+    # mean "the context's own non-blocking stream" to the C ABI, which is NOT ordered against torch's default stream.
+    s = torch.cuda.Stream()
+    assert s.cuda_stream != 0
+    with torch.cuda.stream(s):
+        dev = torch.full((256, 256, 4), 77, dtype=torch.uint8, device="cuda:0")     # the kernel must overwrite every byte
+        gpu.render_volume_device(p, dev.data_ptr(), s.cuda_stream)
+        host = dev.cpu()
+    s.synchronize()
+    assert np.array_equal(host.numpy(), golden.frame(case))
     t = gpu.timing()
     assert t.launches >= 1 and t.kernel_ms > 0
 

@@ -46,7 +46,8 @@ class VrTiming(C.Structure):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvr_hip.so")
+    """In-tree libvr_hip.so; VR_HIP_LIB selects another build of the same library (A/B runs of kernel variants)."""
+    return os.environ.get("VR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvr_hip.so")
 
 
 _lib = None

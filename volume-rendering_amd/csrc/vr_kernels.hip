@@ -183,6 +183,15 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 #elif defined(VR_EXP_ONE_LOAD)                       // measurement only (wrong images): what does the second load cost?
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = f.w0;
+#elif defined(VR_EXP_ASM_LOADS)
+			if (ADDR == kAddr32) {                       // loads the compiler's waitcnt pass does not see: the ray loop waits with an exact count
+				const uint32_t o0 = (uint32_t) (q0 - (const uint8_t *) vol), o1 = (uint32_t) (q1 - (const uint8_t *) vol);
+				asm volatile("global_load_dword %0, %1, %2" : "=v"(f.w0) : "v"(o0), "s"(vol));
+				asm volatile("global_load_dword %0, %1, %2" : "=v"(f.w1) : "v"(o1), "s"(vol));
+			} else {
+				f.w0 = *(const uint32_t *) q0;
+				f.w1 = *(const uint32_t *) q1;
+			}
 #else
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
@@ -258,7 +267,19 @@ __device__ __forceinline__ float select_lanes(uint64_t mask, float x) {
 	asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
 	return r;
 }
-enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5, kIcmpNE = 33, kIcmpSGT = 38 };   // LLVM fcmp / icmp predicate codes for __builtin_amdgcn_fcmpf / sicmp
+enum : int { kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLE = 5, kFcmpUNE = 14, kIcmpNE = 33, kIcmpSGT = 38 };   // LLVM fcmp / icmp predicate codes for __builtin_amdgcn_fcmpf / sicmp
+
+// Exact saturation shortcut, decided per wave.  A sample is composited with weight t = 1 - acc.w (CPURenderer.cpp:34); once a
+// ray's accumulated alpha is EXACTLY 1.0f that weight is exactly 0 and every later sample leaves all four channels bit for
+// bit unchanged (acc + c * 0 == acc, fma(c, 0, acc) == acc for finite c), whatever the early-termination threshold — with the
+// reference's "no optims" threshold of 1.0 its own test `acc.w > threshold` never fires.  When no live lane of the wave has
+// acc.w != 1.0 the wave therefore skips interpolation, transfer function, shading and compositing of the sample; the march
+// itself (k, the fetches, the exit test) goes on unchanged.  Lanes the mask calls open: live and acc.w != 1 (NaN counts as open).
+#ifdef VR_NO_SAT_SHORTCUT
+#define VR_OPEN_LANES(acc_w, live) (live)
+#else
+#define VR_OPEN_LANES(acc_w, live) (__builtin_amdgcn_fcmpf((acc_w), 1.0f, kFcmpUNE) & (live))
+#endif
 
 // 1/sqrt(x) of the light vector in TRILINEAR mode: integer seed + three Newton steps in plain IEEE fp32 operations,
 // identical on CPU and GPU (oracle/vr_oracle.c rsqrt_nr); relative error < 2e-7.
@@ -267,7 +288,9 @@ __device__ __forceinline__ float rsqrt_nr(float x) {
 	const float h = 0.5f * x;
 	y = y * VR_FMA(-(h * y), y, 1.5f);
 	y = y * VR_FMA(-(h * y), y, 1.5f);
+#ifndef VR_EXP_RSQRT2
 	y = y * VR_FMA(-(h * y), y, 1.5f);
+#endif
 	return y;
 }
 
@@ -435,7 +458,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	if (B > 1) {
 		if (tile < nblocked) {
 			const uint32_t blk = tile / (B * B), in = tile - blk * (B * B);
-			const uint32_t by = blk / full_cols, bx = blk - by * full_cols;
+			uint32_t by = blk / full_cols, bx = blk - by * full_cols;
+#ifdef VR_CENTER_FIRST
+			// blocks from the middle of the frame outwards: the long / opaque rays of a centred object start first
+			by = (by & 1u) ? full_rows / 2u - 1u - (by >> 1) : full_rows / 2u + (by >> 1);
+			bx = (bx & 1u) ? full_cols / 2u - 1u - (bx >> 1) : full_cols / 2u + (bx >> 1);
+#endif
 			tile_x = bx * B + in % B; tile_y = by * B + in / B;
 		} else {                                      // ragged right / bottom margins: leftover tiles, row-major
 			uint32_t rest = tile - nblocked;
@@ -545,7 +573,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			__builtin_amdgcn_sched_barrier(0);
 			const uint32_t s = cur_s;
 			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
-			if ((__builtin_amdgcn_sicmp((int) idx, tf_zero_idx, kIcmpSGT) & live) != 0ull) {
+			if ((__builtin_amdgcn_sicmp((int) idx, tf_zero_idx, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 				f4 cur = lds.tf[idx];
 				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
 				if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
@@ -611,7 +639,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #if VR_PREFETCH_DEPTH == 2
 			float k1 = kx + step;                                  // k of the sample after the current one
 #endif
-			auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
+			auto step_sample = [&](TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
 #if VR_PREFETCH_DEPTH == 2
 				const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
 				const float k2 = k1 + step;
@@ -634,10 +662,15 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #ifdef VR_EXP_DUP_LOADS
 				if (LAYOUT == kLayoutBricked && BPV == 1) asm volatile("" :: "v"(cur.d0), "v"(cur.d1));
 #endif
+#ifdef VR_EXP_ASM_LOADS
+				// the two gathers of `cur` are followed by those of the two younger slots (4 loads); any load of a shading block in
+				// between was waited for by the compiler itself
+				if (LAYOUT == kLayoutBricked && BPV == 1 && ADDR == kAddr32) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur.w0), "+v"(cur.w1));
+#endif
 				uint32_t corners;
 				if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
 				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
-				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull) {
+				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 				const float raw = tri_resolve<BPV, LAYOUT>(cur, a);                                    // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
 				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
@@ -656,8 +689,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 						const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
 						const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
 						const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-						const float raw_l = tri_resolve<BPV, LAYOUT>(tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
-						                                                                          VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb), true), a);
+						TriFetch<BPV, LAYOUT> lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
+						                                                        VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb), true);
+#ifdef VR_EXP_ASM_LOADS
+						if (LAYOUT == kLayoutBricked && BPV == 1 && ADDR == kAddr32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lf.w0), "+v"(lf.w1));
+#endif
+						const float raw_l = tri_resolve<BPV, LAYOUT>(lf, a);
 						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 						c.x += diffuse; c.y += diffuse; c.z += diffuse;
 					}
