@@ -145,45 +145,65 @@ void choose_tile_mapping(RayKernelArgs &a) {
 		if (nx > 0.0f && ny > 0.0f && std::fabs(sy[out]) * nx < std::fabs(sx[out]) * ny) a.lane_map = kLaneColumns;
 	}
 	if (v.perspective) return;
-	// orthogonal view: every ray has the same direction; k at the middle of the central ray's path through the cube
-	float k_mid = 0.0f;
-	{
-		float k_in = -1e30f, k_out = 1e30f;
-		for (int i = 0; i < 3; i++) {
-			if (v.direction[i] == 0.0f) continue;
-			const float k1 = (-1.0f - v.origin[i]) / v.direction[i], k2 = (1.0f - v.origin[i]) / v.direction[i];
-			k_in = std::fmax(k_in, std::fmin(k1, k2)); k_out = std::fmin(k_out, std::fmax(k1, k2));
-		}
-		if (k_in < k_out && k_out < 1e29f) k_mid = 0.5f * (std::fmax(k_in, 0.0f) + k_out);
+	// orthogonal view: every ray has the same direction; [k_in, k_out] = the central ray's path through the cube
+	float k_in = -1e30f, k_out = 1e30f;
+	for (int i = 0; i < 3; i++) {
+		if (v.direction[i] == 0.0f) continue;
+		const float k1 = (-1.0f - v.origin[i]) / v.direction[i], k2 = (1.0f - v.origin[i]) / v.direction[i];
+		k_in = std::fmax(k_in, std::fmin(k1, k2)); k_out = std::fmin(k_out, std::fmax(k1, k2));
 	}
-	// texel coordinate of pixel g along the volume axis the screen direction mostly follows: t(g) = t0 + g * dt
-	auto best_phase = [&](const float *s, uint32_t first, uint32_t count, uint32_t centre) {
-		const int ax = major(s);
-		const float dt = s[ax];
-		const float t0 = std::fmaf(k_mid, d[ax], std::fmaf(v.origin[ax], half[ax], off[ax])) - dt * (float) centre;
-		const float hi = 2.0f * half[ax] - 1.0f;
+	if (!(k_in < k_out) || !(k_out < 1e29f)) return;
+	k_in = std::fmax(k_in, 0.0f);
+	// Voxel cell of frame pixel (gx, gy) at depth k along volume axis `ax`, with the KERNEL'S OWN fp32 operations (get_ray,
+	// then fma(k, A, B) / (pos + 1) * half): pixels of an axis-aligned view at the reference's default zoom sit exactly on
+	// cell boundaries, so which neighbour a boundary pixel joins is decided by the last bit — and may change along the ray
+	// when the direction carries rounding noise (pose (180,90,0): components of 4e-8), hence several depths are sampled.
+	auto cell_of = [&](int ax, long gx, long gy, float k) -> long {
+		const float fx = (float) ((int) gx - (int) (v.width / 2u)), fy = (float) ((int) gy - (int) (v.height / 2u));
+		float o = v.origin[ax] + v.right_plane[ax] * fx;
+		o = o + v.up_plane[ax] * fy;
+		float t;
+		if (nearest) t = ((o + v.direction[ax] * k) + 1.0f) * half[ax];
+		else         t = std::fmaf(k, v.direction[ax] * half[ax], std::fmaf(o, half[ax], off[ax]));
+		return (long) std::floor(t);
+	};
+	// Phase 0..7 of the 8-pixel wave columns / rows along one screen direction.  Primary cost (what the vector memory pipeline
+	// charges): 4-pixel groups that leave their aligned cell pair, pixel pairs that straddle two cells.  Secondary: 8-pixel wave
+	// edges that are not 4-cell (128-byte line) boundaries — a wave whose 4x4 cells sit inside one line column touches a
+	// quarter of the lines, and workgroup footprints that end on line boundaries do not fetch their border lines twice
+	// (measured before: 2.0x the compulsory bytes at L2 with 4-pixel alignment only).
+	auto best_phase = [&](bool horizontal, uint32_t first, uint32_t count, uint32_t other_centre) {
+		const float *sdir = horizontal ? sx : sy;
+		const int ax = major(sdir);
+		const long hi = (long) (2.0f * half[ax]) - 1;
 		uint32_t best = 0; long best_cost = -1;
-		for (uint32_t ph = 0; ph < 4; ph++) {
+		for (uint32_t ph = 0; ph < 8; ph++) {
 			long cost = 0;
-			for (long g0 = -(long) ph; g0 < (long) count; g0 += 16) {        // every fourth group is plenty
-				long cell[4]; bool in[4];
-				for (int i = 0; i < 4; i++) {
-					const float t = t0 + dt * (float) ((long) first + g0 + i);
-					in[i] = g0 + i >= 0 && g0 + i < (long) count && t >= 0.0f && t <= hi;
-					cell[i] = (long) std::floor(t);
+			for (int depth = 0; depth < 4; depth++) {
+				const float k = k_in + (k_out - k_in) * (0.125f + 0.25f * (float) depth);
+				for (long g0 = -(long) ph; g0 < (long) count; g0 += 8 * 7) {      // every seventh wave column is plenty
+					long cell[8]; bool in[8];
+					for (int i = 0; i < 8; i++) {
+						const long g = (long) first + g0 + i;
+						cell[i] = horizontal ? cell_of(ax, g, other_centre, k) : cell_of(ax, other_centre, g, k);
+						in[i] = g0 + i >= 0 && g0 + i < (long) count && cell[i] >= 0 && cell[i] <= hi;
+					}
+					for (int q = 0; q < 8; q += 4) {
+						if (in[q] && in[q + 3] && (cell[q] >> 1) != (cell[q + 3] >> 1)) cost += 32;          // the group leaves its aligned cell pair
+						if (in[q] && in[q + 1] && cell[q] != cell[q + 1]) cost += 16;                        // a pixel pair straddles two cells
+						if (in[q + 2] && in[q + 3] && cell[q + 2] != cell[q + 3]) cost += 16;
+					}
+					if (in[0] && in[7] && (cell[0] >> 2) != (cell[7] >> 2)) cost += 1;                       // the wave leaves its line column
 				}
-				if (in[0] && in[3] && (cell[0] >> 1) != (cell[3] >> 1)) cost += 2;      // the group leaves its aligned cell pair
-				if (in[0] && in[1] && cell[0] != cell[1]) cost++;                         // a pixel pair straddles two cells
-				if (in[2] && in[3] && cell[2] != cell[3]) cost++;
 			}
 			if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ph; }
 		}
 		return best;
 	};
-	a.phase_x = best_phase(sx, a.p.x0, a.p.out_width, v.width / 2u);
-	// rows: local row ly maps to frame row gy; with bands of a multiple of 4 rows (or one band) gy = ly + const (mod 4)
+	// rows: local row ly maps to frame row gy; with bands of a multiple of 8 rows (or one band) gy = ly + const (mod 8)
 	const uint32_t gy0 = a.p.band_first * a.p.band_rows;
-	a.phase_y = best_phase(sy, gy0, a.p.out_rows < a.p.band_rows ? a.p.out_rows : a.p.band_rows, v.height / 2u);
+	a.phase_x = best_phase(true, a.p.x0, a.p.out_width, gy0 + std::min(a.p.out_rows, a.p.band_rows) / 2u);
+	a.phase_y = best_phase(false, gy0, a.p.out_rows < a.p.band_rows ? a.p.out_rows : a.p.band_rows, a.p.x0 + a.p.out_width / 2u);
 }
 
 int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
