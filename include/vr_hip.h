@@ -44,8 +44,13 @@ typedef enum vr_status {
 typedef enum vr_sampling {
 	VR_SAMPLE_NEAREST   = 0,  /* Model::sample_data (ModelBase.h:17-23) + transfer_fn[sample / TF_RATIO] (CPURenderer.cpp:31):
 	                             semantics of CPURenderer and GPURenderer1/2/3 */
-	VR_SAMPLE_TRILINEAR = 1   /* GPURenderer4 semantics (GPURenderer4.cu:76-77,91-99,136-141): trilinear volume fetch with
-	                             normalised coordinates + clamp addressing, linearly filtered transfer function */
+	VR_SAMPLE_TRILINEAR = 1,  /* GPURenderer4 semantics (GPURenderer4.cu:76-77,91-99,136-141): trilinear volume fetch with
+	                             normalised coordinates + clamp addressing, linearly filtered transfer function;
+	                             interpolation weights in full fp32 */
+	VR_SAMPLE_TRILINEAR_Q8 = 2 /* the same, with the three volume weights and the transfer-function weight rounded to 8
+	                             fractional bits (rint(w * 256) / 256) before use — the published definition of the linear
+	                             filtering GPURenderer4's tex3D / tex1D calls run on ("9-bit fixed point with 8 bits of
+	                             fractional value"): what the texture unit of renderer 4 computes, as far as it is specified */
 } vr_sampling;
 
 /* How the TRILINEAR path keeps the volume in HBM (NEAREST always reads the reference's linear array).

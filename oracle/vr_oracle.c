@@ -80,9 +80,11 @@ static inline uint32_t sample_nearest(const scene *s, f3 pos) {
  * ran on contracts to FMA as well; no CPU run of it exists).  With f = (pos+1)/2 and pos = origin + dir*k:
  *     xB = f*N - 0.5 = pos*(N/2) + (N/2 - 0.5) = k * (dir*N/2) + fma(origin, N/2, N/2 - 0.5) = fma(k, A, B),
  * A and B computed once per ray.  The HIP kernel executes the same fmaf sequence, so the two agree bit for bit. */
-static inline void axis_setup(float xb, uint32_t n, uint32_t *i0, uint32_t *i1, float *a) {
+static inline void axis_setup(float xb, uint32_t n, uint32_t *i0, uint32_t *i1, float *a, int q8) {
 	float fl = floorf(xb);
 	*a = xb - fl;
+	if (q8)                        /* VR_SAMPLE_TRILINEAR_Q8: weight in 9-bit fixed point with 8 fractional bits (round to nearest even) */
+		*a = rintf(*a * 256.0f) * (1.0f / 256.0f);
 	int32_t i = (int32_t) fl;
 	int32_t lo = i < 0 ? 0 : (i > (int32_t) n - 1 ? (int32_t) n - 1 : i);
 	int32_t j = i + 1;
@@ -97,9 +99,10 @@ static inline float lerp(float a, float b, float t) { return fmaf(t, b - a, a); 
  * of its two consumers (transfer-function coordinate, shading difference). */
 static inline float sample_trilinear_raw(const scene *s, float xb, float yb, float zb) {
 	uint32_t x0, x1, y0, y1, z0, z1; float ax, ay, az;
-	axis_setup(xb, s->dx, &x0, &x1, &ax);
-	axis_setup(yb, s->dy, &y0, &y1, &ay);
-	axis_setup(zb, s->dz, &z0, &z1, &az);
+	const int q8 = s->p->sampling == VR_SAMPLE_TRILINEAR_Q8;
+	axis_setup(xb, s->dx, &x0, &x1, &ax, q8);
+	axis_setup(yb, s->dy, &y0, &y1, &ay, q8);
+	axis_setup(zb, s->dz, &z0, &z1, &az, q8);
 	float v000 = (float) fetch_raw(s, x0, y0, z0), v100 = (float) fetch_raw(s, x1, y0, z0);
 	float v010 = (float) fetch_raw(s, x0, y1, z0), v110 = (float) fetch_raw(s, x1, y1, z0);
 	float v001 = (float) fetch_raw(s, x0, y0, z1), v101 = (float) fetch_raw(s, x1, y0, z1);
@@ -115,7 +118,7 @@ static inline float sample_trilinear_raw(const scene *s, float xb, float yb, flo
 static inline f4 tf_linear(const scene *s, float raw) {
 	uint32_t i0, i1; float a;
 	const float scale = s->bpv == 1 ? (float) VR_TF_SIZE / 255.0f : (float) VR_TF_SIZE / 65535.0f;
-	axis_setup(fmaf(raw, scale, -0.5f), VR_TF_SIZE, &i0, &i1, &a);
+	axis_setup(fmaf(raw, scale, -0.5f), VR_TF_SIZE, &i0, &i1, &a, s->p->sampling == VR_SAMPLE_TRILINEAR_Q8);
 	f4 c0 = s->tf[i0], c1 = s->tf[i1];
 	f4 r = { lerp(c0.x, c1.x, a), lerp(c0.y, c1.y, a), lerp(c0.z, c1.z, a), lerp(c0.w, c1.w, a) };
 	return r;
@@ -217,9 +220,96 @@ static inline f3 march_point(int fused, f3 origin, f3 direction, float k) {
 	return f3_add(origin, f3_scale(direction, k));
 }
 
+/* ---- VRO_SAMPLE_TRILINEAR_F64: the TRILINEAR model evaluated in double precision -----------------------------------------
+ * Same rays, same fp32 k sequence (k += ray_step in float, VR/CPURenderer.cpp:37), same cell / weight definition
+ * (xB = pos * N/2 + N/2 - 1/2, clamp addressing, GPURenderer4.cu:76-77,136-141), but every product, lerp, square root and
+ * composite in IEEE double.  Used by tests only, to bound the fp32 rounding error of the product's TRILINEAR arithmetic (and,
+ * against VR_SAMPLE_TRILINEAR_Q8, the effect of 8-bit filter weights) independently of the restatement's own fmaf sequence. */
+static inline double tri_f64(const scene *s, double xb, double yb, double zb) {
+	double c[3] = { xb, yb, zb }, a[3];
+	uint32_t lo[3], hi[3];
+	const uint32_t n[3] = { s->dx, s->dy, s->dz };
+	for (int i = 0; i < 3; i++) {
+		double fl = floor(c[i]);
+		a[i] = c[i] - fl;
+		long j = (long) fl, m = (long) n[i] - 1;
+		lo[i] = (uint32_t) (j < 0 ? 0 : (j > m ? m : j));
+		hi[i] = (uint32_t) (j + 1 < 0 ? 0 : (j + 1 > m ? m : j + 1));
+	}
+	double v[2][2][2];
+	for (int z = 0; z < 2; z++) for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++)
+		v[z][y][x] = (double) fetch_raw(s, x ? hi[0] : lo[0], y ? hi[1] : lo[1], z ? hi[2] : lo[2]);
+	double c00 = v[0][0][0] + a[0] * (v[0][0][1] - v[0][0][0]), c10 = v[0][1][0] + a[0] * (v[0][1][1] - v[0][1][0]);
+	double c01 = v[1][0][0] + a[0] * (v[1][0][1] - v[1][0][0]), c11 = v[1][1][0] + a[0] * (v[1][1][1] - v[1][1][0]);
+	double c0 = c00 + a[1] * (c10 - c00), c1 = c01 + a[1] * (c11 - c01);
+	return c0 + a[2] * (c1 - c0);
+}
+
+static void render_ray_f64(const scene *s, int px, int py, uint8_t *out_px, counters *c) {
+	const vr_params *p = s->p;
+	f3 origin, direction;
+	float kx, ky;
+	get_ray(&p->view, px, py, &origin, &direction);
+	if (!intersect(s, origin, direction, &kx, &ky))
+		return;
+	c->rays_hit++;
+	while (kx <= ky) {                                   /* empty space leaping: the reference's fp32 loop, unchanged */
+		f3 pt = march_point(1, origin, direction, kx);
+		c->esl_probes++;
+		if (p->esl && sample_data_esl(s, pt))
+			leap_empty_space(s, pt, direction, &kx);
+		else
+			break;
+		kx += p->ray_step;
+	}
+	if (kx > ky)
+		return;
+	const double o[3] = { origin.x, origin.y, origin.z }, d[3] = { direction.x, direction.y, direction.z };
+	const double half[3] = { 0.5 * s->dx, 0.5 * s->dy, 0.5 * s->dz };
+	const double lp[3] = { p->view.light_pos[0], p->view.light_pos[1], p->view.light_pos[2] };
+	const double raw_scale = s->bpv == 1 ? 255.0 : 65535.0;
+	double acc[4] = { 0, 0, 0, 0 };
+	while (kx <= ky) {
+		c->samples++;
+		double pos[3], tb[3];
+		for (int i = 0; i < 3; i++) { pos[i] = o[i] + d[i] * (double) kx; tb[i] = pos[i] * half[i] + half[i] - 0.5; }
+		const double raw = tri_f64(s, tb[0], tb[1], tb[2]);
+		double t = raw / raw_scale * VR_TF_SIZE - 0.5;
+		if (t < 0) t = 0;
+		if (t > VR_TF_SIZE - 1) t = VR_TF_SIZE - 1;
+		const int i0 = (int) floor(t), i1 = i0 + 1 < VR_TF_SIZE ? i0 + 1 : i0;
+		const double w = t - floor(t);
+		const f4 t0 = s->tf[i0], t1 = s->tf[i1];
+		double cur[4] = { t0.x + w * ((double) t1.x - t0.x), t0.y + w * ((double) t1.y - t0.y),
+		                  t0.z + w * ((double) t1.z - t0.z), t0.w + w * ((double) t1.w - t0.w) };
+		if (cur[3] > 0.05 && p->light_kd > 0.01f) {
+			double l[3] = { lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2] };
+			const double inv = 1.0 / sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+			const double raw_l = tri_f64(s, tb[0] + l[0] * inv * 0.01 * half[0], tb[1] + l[1] * inv * 0.01 * half[1],
+			                             tb[2] + l[2] * inv * 0.01 * half[2]);
+			const double diffuse = (raw_l - raw) / raw_scale * (double) p->light_kd;
+			cur[0] += diffuse; cur[1] += diffuse; cur[2] += diffuse;
+			c->shade_fetches++;
+		}
+		const double tr = 1.0 - acc[3];
+		for (int i = 0; i < 4; i++) acc[i] += cur[i] * tr;
+		if (acc[3] > (double) p->ray_threshold)
+			break;
+		kx += p->ray_step;
+	}
+	for (int i = 0; i < 4; i++) {
+		long q = (long) (acc[i] * 256.0);
+		out_px[i] = (uint8_t) (q < 0 ? 0 : (q > 255 ? 255 : q));
+	}
+}
+
 /* VR/CPURenderer.cpp:11-41 render_ray (NEAREST) and VR/GPURenderer4.cu:53-87 (TRILINEAR) */
 static void render_ray(const scene *s, int px, int py, uint8_t *out_px, counters *c) {
 	const vr_params *p = s->p;
+	if (p->sampling == VRO_SAMPLE_TRILINEAR_F64) {
+		render_ray_f64(s, px, py, out_px, c);
+		return;
+	}
 	f3 origin, direction;
 	float kx, ky;
 	get_ray(&p->view, px, py, &origin, &direction);

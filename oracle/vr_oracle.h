@@ -20,6 +20,9 @@
 extern "C" {
 #endif
 
+/* vr_params.sampling value understood by the ORACLE ONLY (the product rejects it): the TRILINEAR model in double precision */
+#define VRO_SAMPLE_TRILINEAR_F64 100u
+
 typedef struct vro_stats {
 	uint64_t rays_hit;        /* rays that intersect the cube */
 	uint64_t esl_probes;      /* iterations of the empty-space-leaping loop */

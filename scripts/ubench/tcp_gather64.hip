@@ -20,12 +20,11 @@ __global__ __launch_bounds__(256) void k(const uint8_t *buf, uint32_t *out, int 
 #pragma unroll
 		for (int u = 0; u < 8; u++) {
 			const uint8_t *p = buf + off + walk + u * 128 * 1024;
-			if (W == 4) { uint32_t v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p)); asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)); acc ^= v; }
-			else { uint2 v; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p)); asm volatile("s_waitcnt vmcnt(7)" : "+v"(v)); acc ^= v.x ^ v.y; }
+			if (W == 4) acc ^= *(const uint32_t *) p;
+			else { const uint2 v = *(const uint2 *) p; acc ^= v.x ^ v.y; }     // global_load_dwordx2; the address may be only 4-byte aligned
 		}
 		walk = (walk + 8192) & 16383;   // stays inside this wave's 16 KiB window
 	}
-	asm volatile("s_waitcnt vmcnt(0)");
 	out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 

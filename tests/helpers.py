@@ -160,6 +160,15 @@ class Golden:
         return self.arrays[f"case{case['id']}_frame"]
 
 
+VRO_SAMPLE_TRILINEAR_F64 = 100      # oracle-only sampling code (oracle/vr_oracle.h): the TRILINEAR model in double precision
+
+
+def frame_delta(a, b):
+    """(mean abs channel delta, fraction of pixels that differ, max abs channel delta) of two RGBA8 frames"""
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    return float(d.mean()), float((d.max(axis=-1) != 0).mean()), int(d.max())
+
+
 def compare_frames(a, b):
     """(#differing pixels, max abs channel delta)"""
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))

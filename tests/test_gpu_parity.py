@@ -75,6 +75,47 @@ def test_trilinear_bit_exact_vs_oracle(vr, gpu, golden, oracle):
     assert checked >= 30
 
 
+def test_trilinear_q8_bit_exact_vs_oracle(vr, gpu, golden, oracle):
+    """VR_SAMPLE_TRILINEAR_Q8 (8-bit filter weights, the texture unit's published precision): HIP == restatement, bit for bit."""
+    gpu.set_window_buffer(256, 256)
+    current, checked = None, 0
+    for case in golden.cases(with_frames_only=True):
+        if "bench256" in case["label"] and "view5" not in case["label"] and "view2" not in case["label"]:
+            continue
+        if case["volume"] != current:
+            st = load_volume(gpu, golden, case["volume"])
+            current = case["volume"]
+        p = golden.params(case, vr.SAMPLE_TRILINEAR_Q8)
+        out = gpu.render_volume(p)
+        ref = oracle.render(p, golden.voxels(case["volume"]), st["tf"], st["esl"], threads=16)
+        ndiff, maxd = compare_frames(out, ref)
+        assert ndiff == 0, f"{case['label']}: {ndiff} pixels differ, max delta {maxd}"
+        checked += 1
+    assert checked >= 30
+
+
+def test_trilinear_stated_tolerances_on_the_gpu(vr, gpu, golden, oracle):
+    """The tolerances of tests/test_trilinear_pinning.py with the HIP frames themselves: T1 against the double-precision
+    model, T2 8-bit against fp32 weights, T3 against the reference's CPURenderer frames (all 46 golden cases)."""
+    import test_trilinear_pinning as tp
+    from helpers import VRO_SAMPLE_TRILINEAR_F64, frame_delta
+    gpu.set_window_buffer(256, 256)
+    current = None
+    for case in golden.cases(with_frames_only=True):
+        if case["volume"] != current:
+            st = load_volume(gpu, golden, case["volume"])
+            current = case["volume"]
+        tri = gpu.render_volume(golden.params(case, vr.SAMPLE_TRILINEAR))
+        q8 = gpu.render_volume(golden.params(case, vr.SAMPLE_TRILINEAR_Q8))
+        f64 = oracle.render(golden.params(case, VRO_SAMPLE_TRILINEAR_F64), golden.voxels(case["volume"]), st["tf"], st["esl"], threads=16)
+        _, differing, maxd = frame_delta(tri, f64)
+        assert differing <= tp.T1_MAX_DIFFERING and maxd <= tp.T1_MAX_DELTA, (case["label"], differing, maxd)
+        mean, differing, maxd = frame_delta(tri, q8)
+        assert mean <= tp.T2_MAX_MEAN and differing <= tp.T2_MAX_DIFFERING and maxd <= tp.T2_MAX_DELTA, (case["label"], mean, differing, maxd)
+        mean, _, _ = frame_delta(tri, golden.frame(case))
+        assert mean <= tp.T3_MAX_MEAN[case["volume"]], (case["label"], mean)
+
+
 def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
     """VR_LAYOUT_LINEAR and the brick copies of VR_LAYOUT_BRICKED hold the same voxels: identical images (all equal the oracle)."""
     for name, labels in (("bucky", ("bench64_view1_default", "bench64_view6_default", "inside_persp")),

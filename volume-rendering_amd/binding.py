@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 SAMPLE_NEAREST = 0      # vr_sampling.VR_SAMPLE_NEAREST   — CPURenderer / GPURenderer1-3 semantics
-SAMPLE_TRILINEAR = 1    # vr_sampling.VR_SAMPLE_TRILINEAR — GPURenderer4 semantics
+SAMPLE_TRILINEAR = 1    # vr_sampling.VR_SAMPLE_TRILINEAR — GPURenderer4 semantics, fp32 filter weights
+SAMPLE_TRILINEAR_Q8 = 2  # vr_sampling.VR_SAMPLE_TRILINEAR_Q8 — the same with 8-bit filter weights (the texture unit's definition)
 LAYOUT_LINEAR = 0        # vr_layout
 LAYOUT_BRICKED = 1
 TF_SIZE = 128

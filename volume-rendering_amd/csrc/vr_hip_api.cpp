@@ -105,7 +105,7 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 		return fail(c, VR_ERR_INVALID, "ray_threshold / light_kd must be finite");
 	if (p->esl && (p->esl_block_dims == 0 || p->esl_block_dims > 65535u || !finite3(p->esl_block_size)))   // unsigned short in the reference
 		return fail(c, VR_ERR_INVALID, "esl_block_dims must be in 1..65535 and esl_block_size finite when esl is on");
-	if (p->sampling != VR_SAMPLE_NEAREST && p->sampling != VR_SAMPLE_TRILINEAR)
+	if (p->sampling != VR_SAMPLE_NEAREST && p->sampling != VR_SAMPLE_TRILINEAR && p->sampling != VR_SAMPLE_TRILINEAR_Q8)
 		return fail(c, VR_ERR_INVALID, "unknown sampling mode");
 	if (p->out_width == 0 || p->out_rows == 0 || p->out_width > 65535u || p->out_rows > 65535u)
 		return fail(c, VR_ERR_INVALID, "out_width / out_rows out of range");
@@ -241,7 +241,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
 	a.brick_plane = kPlaneXY;
-	if (p->sampling == VR_SAMPLE_TRILINEAR && a.layout == kLayoutBricked && !c->force_wide) {
+	if (p->sampling != VR_SAMPLE_NEAREST && a.layout == kLayoutBricked && !c->force_wide) {
 		uint32_t plane = kPlaneXY;
 		if (c->brick_plane_force >= 0) plane = (uint32_t) c->brick_plane_force;
 		else {

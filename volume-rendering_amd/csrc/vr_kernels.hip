@@ -232,11 +232,16 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 }
 
 // returns the interpolated RAW voxel value
-template <int BPV, int LAYOUT>
+// VR_SAMPLE_TRILINEAR_Q8: an interpolation weight in 9-bit fixed point with 8 fractional bits, rint(w * 256) / 256 (v_rndne_f32)
+template <bool Q8> __device__ __forceinline__ float filter_weight(float w) {
+	return Q8 ? __builtin_rintf(w * 256.0f) * (1.0f / 256.0f) : w;
+}
+
+template <int BPV, int LAYOUT, bool Q8>
 __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a) {
-	const float ax = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.xb, 0.0f, a.max_x));
-	const float ay = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.yb, 0.0f, a.max_y));
-	const float az = __builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.zb, 0.0f, a.max_z));
+	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.xb, 0.0f, a.max_x)));
+	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.yb, 0.0f, a.max_y)));
+	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.zb, 0.0f, a.max_z)));
 	float v000, v100, v010, v110, v001, v101, v011, v111;
 	if (LAYOUT == kLayoutBricked) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
 	typedef LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)> L;
+	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
 	constexpr bool kUseLut = L::max_dim != 0;
 	constexpr uint32_t kThreads = L::threads;
 	__shared__ LdsTables lds;
@@ -671,14 +677,14 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
 				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
 				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
-				const float raw = tri_resolve<BPV, LAYOUT>(cur, a);                                    // GPURenderer4.cu:76
+				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(cur, a);                                    // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
 				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
 				if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
 					f4 c;
 					{
 						const uint32_t i = (uint32_t) (int) tb;
-						const float w = __builtin_amdgcn_fractf(tb);
+						const float w = filter_weight<kQ8>(__builtin_amdgcn_fractf(tb));
 						const f4 c0 = lds.tf[i], dc = lds.dtf[i];
 						c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y);
 						c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
@@ -694,7 +700,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #ifdef VR_EXP_ASM_LOADS
 						if (LAYOUT == kLayoutBricked && BPV == 1 && ADDR == kAddr32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lf.w0), "+v"(lf.w1));
 #endif
-						const float raw_l = tri_resolve<BPV, LAYOUT>(lf, a);
+						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a);
 						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 						c.x += diffuse; c.y += diffuse; c.z += diffuse;
 					}
@@ -751,29 +757,32 @@ static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, 
 	return hipGetLastError();
 }
 
-template <int BPV>
-static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
-                             const uint32_t *esl, void *out, hipStream_t stream) {
-	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
+template <int SAMPLING, int BPV>
+static hipError_t launch_sampling(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
+                                  const uint32_t *esl, void *out, hipStream_t stream) {
+	constexpr bool nearest = SAMPLING == VR_SAMPLE_NEAREST;
 	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
 	if (bricked != nullptr) {
 		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
 		if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
-			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream)
-			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
 		if (a.force_wide != 1 && max_dim <= LutCfg<kAddrLut64>::max_dim)
-			return nearest ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream)
-			               : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream);
-		if (!nearest)
-			return launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return launch_variant<SAMPLING, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+		if constexpr (!nearest)
+			return launch_variant<SAMPLING, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);
 	}
 	// the reference's linear array; 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12)
 	const bool wide = a.force_wide || ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);
-	if (nearest)
-		return wide ? launch_variant<VR_SAMPLE_NEAREST, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
-		            : launch_variant<VR_SAMPLE_NEAREST, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
-	return wide ? launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
-	            : launch_variant<VR_SAMPLE_TRILINEAR, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
+	return wide ? launch_variant<SAMPLING, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
+	            : launch_variant<SAMPLING, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
+}
+
+template <int BPV>
+static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
+                             const uint32_t *esl, void *out, hipStream_t stream) {
+	if (a.p.sampling == VR_SAMPLE_NEAREST) return launch_sampling<VR_SAMPLE_NEAREST, BPV>(a, linear, bricked, tf, esl, out, stream);
+	if (a.p.sampling == VR_SAMPLE_TRILINEAR_Q8) return launch_sampling<VR_SAMPLE_TRILINEAR_Q8, BPV>(a, linear, bricked, tf, esl, out, stream);
+	return launch_sampling<VR_SAMPLE_TRILINEAR, BPV>(a, linear, bricked, tf, esl, out, stream);
 }
 
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bpv, const float *tf,
