@@ -153,7 +153,9 @@ int vr_hip_set_tile_mapping(vr_ctx *ctx, int32_t lane_map, uint32_t phase_x, uin
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
  *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.
  * vr_hip_render_device: `dev_rgba` is a DEVICE pointer (renderer ids 3-4, GPURenderer23.cu:72-81) — clear + kernel on
- *   `stream` (a hipStream_t, NULL = the context's own stream).  Asynchronous with respect to the host.
+ *   `stream` (a hipStream_t).  NULL means the context's OWN non-blocking stream, which is not ordered against the legacy
+ *   default stream: a caller that fills or reads `dev_rgba` on another stream must pass that stream (or synchronise itself).
+ *   Asynchronous with respect to the host.
  * Return 0 ok / VR_ERR_INVALID on NULL arguments like the reference (GPURenderer1.cu:101-102). */
 int vr_hip_render(vr_ctx *ctx, const vr_params *params, uint8_t *host_rgba);
 int vr_hip_render_device(vr_ctx *ctx, const vr_params *params, void *dev_rgba, void *stream);
@@ -177,6 +179,52 @@ int vr_hip_volume_histogram(vr_ctx *ctx, uint64_t *hist256_out, float *kernel_ms
 int vr_hip_generate_volume(vr_ctx *ctx, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bytes_per_voxel);
 /* copy the resident volume back (unpadded, x-fastest) — for checksums and for feeding the CPU baseline */
 int vr_hip_download_volume(vr_ctx *ctx, void *host_out, uint64_t bytes);
+
+/* ---- several MI355X behind one call (the reference drives one device, VolR.cpp:141-172) ----
+ * One process, one context + stream per device, volume / TF / ESL replicated; a frame is cut into interleaved bands of rows
+ * (band b -> devices[b mod n]), every device renders its bands, the RGBA8 bands travel to devices[0] over xGMI — RCCL
+ * ncclSend / ncclRecv (communicators from ncclCommInitAll; librccl is loaded on demand) or peer copies when RCCL is not
+ * available or a device is listed twice — and a copy kernel there de-interleaves them.  `params` describe the WHOLE frame
+ * (partition fields are ignored); the image equals the single-device image byte for byte.  Calls are synchronous.
+ * A one-entry list is the single-device path.  The reference's `renderers[id]->render_volume()` reaches this through
+ * volr::HipRenderer's device-list constructor (volume-rendering_amd/csrc/host/Renderer.h). */
+typedef struct vr_multi vr_multi;
+int  vr_hip_multi_create(int n, const int *devices, vr_multi **out);
+void vr_hip_multi_destroy(vr_multi *m);
+const char *vr_hip_multi_last_error(const vr_multi *m);
+int  vr_hip_multi_count(const vr_multi *m);
+vr_ctx *vr_hip_multi_context(vr_multi *m, int rank);               /* the per-device context (feeders, layout knobs, timing) */
+const char *vr_hip_multi_transport(const vr_multi *m);             /* "rccl" | "peer-copy" | "single" */
+int  vr_hip_multi_set_window(vr_multi *m, uint32_t width, uint32_t height);
+int  vr_hip_multi_set_transfer_fn(vr_multi *m, const float *tf_premult_rgba, const uint32_t *esl_bits);
+int  vr_hip_multi_set_volume(vr_multi *m, const void *host_voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t bytes_per_voxel);
+int  vr_hip_multi_generate_volume(vr_multi *m, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bytes_per_voxel);
+int  vr_hip_multi_render(vr_multi *m, const vr_params *params, uint8_t *host_rgba);           /* whole frame -> host buffer */
+int  vr_hip_multi_render_device(vr_multi *m, const vr_params *params, void *dev_rgba);        /* whole frame -> buffer on devices[0] */
+int  vr_hip_multi_timing(vr_multi *m, float *per_device_kernel_ms, float *total_ms);
+/* the partition itself: frame row y belongs to device *rank_out and is row *local_row_out of that device's band buffer */
+void vr_hip_multi_band_map(uint32_t n, uint32_t band_rows, uint32_t y, uint32_t *rank_out, uint32_t *local_row_out);
+uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
+
+/* ---- what the resident volume occupies in HBM, and giving some of it back ----
+ * The bricked layout keeps the reference's linear array (feeders, download, rebuilding copies) next to one brick copy per chunk
+ * plane; the second and third copy are only built while at least half of the device memory stays free, so `brick_copies` may be
+ * smaller than `brick_copies_wanted` — a speed cliff this call makes visible (axis-aligned views along x / y then read the
+ * (x,y) copy).  vr_hip_release_linear_copy frees the linear array once nothing will need it again: afterwards rendering works
+ * as before, while vr_hip_volume_minmax / _histogram / vr_hip_download_volume / vr_hip_set_layout return VR_ERR_NOT_READY
+ * until the next set_volume.  Refused (VR_ERR_INVALID) when the linear array is the only copy a render path can read. */
+typedef struct vr_volume_info {
+	uint32_t dim_x, dim_y, dim_z, bytes_per_voxel;
+	uint32_t layout;                /* vr_layout actually in use */
+	uint32_t brick_copies;          /* brick copies resident (0..3) */
+	uint32_t brick_copies_wanted;   /* copies the layout policy asks for at this size (3: u8 with edges <= 1024, else 1; 0: linear) */
+	uint32_t brick_planes;          /* bit i set = the copy with chunk plane i (0 (x,y), 1 (x,z), 2 (y,z)) is resident */
+	uint32_t linear_resident;       /* 1 while the linear array is in HBM */
+	uint32_t reserved;
+	uint64_t linear_bytes, bricked_bytes;
+} vr_volume_info;
+int vr_hip_volume_info(vr_ctx *ctx, vr_volume_info *out);
+int vr_hip_release_linear_copy(vr_ctx *ctx);
 
 /* ---- introspection ---- */
 int vr_hip_device_info(vr_ctx *ctx, char *name_out, size_t name_cap, uint32_t *compute_units, uint64_t *hbm_bytes);

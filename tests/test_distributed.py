@@ -132,3 +132,27 @@ def test_assemble_is_the_inverse_of_the_band_map():
                     local[ly] = frame[gy]
             parts.append(local)
         assert torch.equal(s.assemble(torch.stack(parts)), frame), (world, band)
+
+
+def test_multi_device_band_map_matches_the_process_split():
+    """The single-process multi-GPU path (vr_hip_multi_*, volume-rendering_amd/csrc/vr_multi.cpp) and the one-process-per-GPU
+    path (FrameSplit) use the same partition: frame row y -> (rank, row of that rank's band buffer), and the same default band
+    height.  Pure host functions of the C ABI, no GPU needed."""
+    import ctypes as C
+    vr = importlib.import_module("volume-rendering_amd")
+    dmod = importlib.import_module("volume-rendering_amd.distributed")
+    L = vr.lib()
+    for H, world, band in ((37, 1, None), (2048, 2, None), (2048, 8, None), (1080, 4, None), (37, 3, 4), (200, 2, 19), (64, 8, 16)):
+        band_rows = band or dmod.default_band_rows(H, world)
+        assert L.vr_hip_multi_default_band_rows(H, world) == dmod.default_band_rows(H, world)
+        splits = [dmod.FrameSplit(5, H, world, r, band_rows) for r in range(world)]
+        # assemble() of buffers whose rows are tagged (rank, local row) tells where FrameSplit takes every frame row from
+        tagged = torch.zeros((world, splits[0].local_rows, 5, 4), dtype=torch.int32)
+        for r in range(world):
+            tagged[r, :, :, 0] = r
+            tagged[r, :, :, 1] = torch.arange(splits[0].local_rows).view(-1, 1)
+        frame = splits[0].assemble(tagged)
+        for y in range(H):
+            rank, local_row = C.c_uint32(), C.c_uint32()
+            L.vr_hip_multi_band_map(world, band_rows, y, C.byref(rank), C.byref(local_row))
+            assert (rank.value, local_row.value) == (int(frame[y, 0, 0]), int(frame[y, 0, 1])), (H, world, band_rows, y)

@@ -280,6 +280,102 @@ def test_set_volume_from_device_memory(vr, gpu, golden):
     assert np.array_equal(gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), golden.frame(case))
 
 
+def test_multi_device_frame_equals_single_device(vr, gpu, golden):
+    """vr_hip_multi_*: one call, several per-device contexts, interleaved bands gathered on devices[0] and de-interleaved there.
+    On a one-GPU box the list names device 0 once (the single path), twice and three times (band split + peer-copy gather +
+    assemble kernel on real hardware); with distinct devices the gather is RCCL send/recv.  Image == the single-device image."""
+    import torch
+    for label, sampling in (("bench256_view5_default", vr.SAMPLE_NEAREST), ("window_199x178_view1", vr.SAMPLE_TRILINEAR)):
+        case = [c for c in golden.cases(True) if c["label"] == label][0]
+        st = load_volume(gpu, golden, case["volume"])
+        p = golden.params(case, sampling)
+        gpu.set_window_buffer(p.view.width, p.view.height)
+        want = gpu.render_volume(p)
+        for devices in ([0], [0, 0], [0, 0, 0]):
+            m = vr.MultiRenderer(devices)
+            try:
+                assert m.transport == ("single" if len(devices) == 1 else "peer-copy")
+                m.set_window_buffer(p.view.width, p.view.height)
+                m.set_transfer_fn(st["tf"], st["esl"])
+                m.set_volume(golden.voxels(case["volume"]))
+                assert np.array_equal(m.render_volume(p), want), (label, devices)
+                dev = torch.full((p.view.height, p.view.width, 4), 9, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                m.render_volume_device(p, dev.data_ptr())
+                assert np.array_equal(dev.cpu().numpy(), want), (label, devices)
+                per, total = m.timing()
+                assert len(per) == len(devices) and all(x > 0 for x in per) and total > 0
+            finally:
+                m.close()
+
+
+def test_volume_info_and_release_of_the_linear_copy(vr, golden):
+    """vr_hip_volume_info reports the copies that were actually built; after vr_hip_release_linear_copy rendering is unchanged
+    and everything that needs the linear array says so instead of reading freed memory."""
+    r = vr.HipRenderer(0)
+    try:
+        st = golden.volume_state("bucky")
+        r.set_transfer_fn(st["tf"], st["esl"])
+        r.set_volume(golden.voxels("bucky"))
+        r.set_window_buffer(256, 256)
+        info = r.volume_info()
+        assert (info.dim_x, info.dim_y, info.dim_z, info.bytes_per_voxel) == (32, 32, 32, 1)
+        assert info.layout == vr.LAYOUT_BRICKED and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7
+        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.bricked_bytes == 3 * 4 * 32 ** 3
+        case = [c for c in golden.cases(True) if c["label"] == "bench256_view1_default"][0]
+        before = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
+        r.release_linear_copy()
+        info = r.volume_info()
+        assert info.linear_resident == 0 and info.linear_bytes == 0 and info.brick_copies == 3
+        after = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
+        assert all(np.array_equal(a, b) for a, b in zip(before, after))
+        assert np.array_equal(after[0], golden.frame(case))
+        for call in (r.volume_minmax, r.volume_histogram, r.download_volume, lambda: r.set_layout(vr.LAYOUT_LINEAR)):
+            with pytest.raises(vr.VrError) as e:
+                call()
+            assert e.value.code == 5 and "released" in str(e.value)            # VR_ERR_NOT_READY
+        r.set_volume(golden.voxels("bucky"))                                   # a new volume brings everything back
+        assert r.volume_info().linear_resident == 1 and r.volume_minmax()[1] == 8
+        r.set_layout(vr.LAYOUT_LINEAR)
+        with pytest.raises(vr.VrError) as e:
+            r.release_linear_copy()                                            # the linear array is the only copy now
+        assert e.value.code == 1
+    finally:
+        r.close()
+
+
+def test_long_thin_volume_axis_aligned_zero_direction(vr, gpu, oracle):
+    """An exactly-zero direction component makes intersect() substitute 1e-5 (RaycasterBase.h:33-35): rays whose origin lies up
+    to ky * 1e-5 outside a face still count as hits and march at that out-of-cube coordinate — with an edge of 40000 voxels that
+    is more than one texel, so the host must clamp the fetch coordinates (clamp_fetch).  GPU == oracle, both sampling modes."""
+    n = (40000, 8, 8)
+    rng = np.random.default_rng(7)
+    vox = rng.integers(0, 256, size=(n[2], n[1], n[0]), dtype=np.uint8)
+    tf, esl, bd, bs, step = oracle.scene_for(vox)
+    gpu.set_transfer_fn(tf, esl)
+    gpu.set_volume(vox)
+    gpu.set_window_buffer(96, 64)
+    for persp in (0, 1):
+        for angles in ((0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (0.0, 90.0, 0.0)):
+            v = vr.scene.custom_view(96, 64, persp, angles, 2.5)
+            if not persp and angles == (0.0, 0.0, 0.0):
+                # put pixel column 10 just OUTSIDE the x = -1 face, by 3.2e-5 < ky * 1e-5 = 3.5e-5: reported as a hit for the last
+                # steps of the march, at texel coordinate -1.14 along the 40000-voxel edge
+                assert v.direction[0] == 0.0 and v.right_plane[1] == 0.0
+                v.origin[0] = float(np.float32(-1.0 - 3.2e-5) - np.float32(v.right_plane[0]) * np.float32(10 - 48))
+            for samp in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+                p = vr.VrParams()
+                p.view = v
+                p.ray_step, p.ray_threshold, p.light_kd = float(step) * 400.0, 0.95, 0.6
+                p.esl, p.esl_block_dims, p.sampling = 1, bd, samp
+                for j in range(3):
+                    p.esl_block_size[j] = float(bs[j])
+                p = vr.whole_frame(p)
+                out = gpu.render_volume(p)
+                ref = oracle.render(p, vox, tf, esl, threads=16)
+                assert compare_frames(out, ref) == (0, 0), (persp, angles, samp)
+
+
 def test_cpp_renderer_mirror(vr, gpu, golden):
     """The host C++ mirror: RaycasterBase::reset_transfer_fn/set_volume -> HipRenderer(raycaster).render_volume()."""
     vox = golden.voxels("bucky")

@@ -14,9 +14,9 @@ from .binding import (  # noqa: F401
     SAMPLE_NEAREST, SAMPLE_TRILINEAR, SAMPLE_TRILINEAR_Q8, TF_SIZE, ESL_VOLUME_SIZE, LAYOUT_LINEAR, LAYOUT_BRICKED,
 )
 from .scene import Scene, benchmark_view, whole_frame, band_partition  # noqa: F401
-from .renderer import HipRenderer  # noqa: F401
+from .renderer import HipRenderer, MultiRenderer  # noqa: F401
 
 __all__ = [
     "VrError", "VrParams", "VrView", "VrTiming", "lib", "library_path", "SAMPLE_NEAREST", "SAMPLE_TRILINEAR", "SAMPLE_TRILINEAR_Q8",
-    "TF_SIZE", "ESL_VOLUME_SIZE", "LAYOUT_LINEAR", "LAYOUT_BRICKED", "Scene", "benchmark_view", "whole_frame", "band_partition", "HipRenderer",
+    "TF_SIZE", "ESL_VOLUME_SIZE", "LAYOUT_LINEAR", "LAYOUT_BRICKED", "Scene", "benchmark_view", "whole_frame", "band_partition", "HipRenderer", "MultiRenderer",
 ]

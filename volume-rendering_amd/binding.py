@@ -42,6 +42,12 @@ class VrParams(C.Structure):
         return other
 
 
+class VrVolumeInfo(C.Structure):
+    _fields_ = [("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("dim_z", C.c_uint32), ("bytes_per_voxel", C.c_uint32),
+                ("layout", C.c_uint32), ("brick_copies", C.c_uint32), ("brick_copies_wanted", C.c_uint32), ("brick_planes", C.c_uint32),
+                ("linear_resident", C.c_uint32), ("reserved", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64)]
+
+
 class VrTiming(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint64), ("kernel_ms_sum", C.c_double)]
 
@@ -93,6 +99,23 @@ def lib():
         "vr_hip_generate_volume": (C.c_int, [vp, u32, u32, u32, u32]),
         "vr_hip_download_volume": (C.c_int, [vp, vp, u64]),
         "vr_hip_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, P(u32), P(u64)]),
+        "vr_hip_volume_info": (C.c_int, [vp, P(VrVolumeInfo)]),
+        "vr_hip_release_linear_copy": (C.c_int, [vp]),
+        "vr_hip_multi_create": (C.c_int, [C.c_int, P(C.c_int), P(vp)]),
+        "vr_hip_multi_destroy": (None, [vp]),
+        "vr_hip_multi_last_error": (C.c_char_p, [vp]),
+        "vr_hip_multi_count": (C.c_int, [vp]),
+        "vr_hip_multi_context": (vp, [vp, C.c_int]),
+        "vr_hip_multi_transport": (C.c_char_p, [vp]),
+        "vr_hip_multi_set_window": (C.c_int, [vp, u32, u32]),
+        "vr_hip_multi_set_transfer_fn": (C.c_int, [vp, vp, vp]),
+        "vr_hip_multi_set_volume": (C.c_int, [vp, vp, u32, u32, u32, u32]),
+        "vr_hip_multi_generate_volume": (C.c_int, [vp, u32, u32, u32, u32]),
+        "vr_hip_multi_render": (C.c_int, [vp, P(VrParams), vp]),
+        "vr_hip_multi_render_device": (C.c_int, [vp, P(VrParams), vp]),
+        "vr_hip_multi_timing": (C.c_int, [vp, f32p, f32p]),
+        "vr_hip_multi_band_map": (None, [u32, u32, u32, P(u32), P(u32)]),
+        "vr_hip_multi_default_band_rows": (u32, [u32, u32]),
         "vr_host_benchmark_view": (C.c_int, [u32, u32, u32, f32p, C.c_float, P(VrView)]),
         "vr_host_benchmark_view_index": (C.c_int, [u32, u32, u32, P(VrView)]),
         "vr_host_raycaster_set_volume": (C.c_int, [vp, u32, u32, u32, vp]),

@@ -124,8 +124,10 @@ bool read_pvm_volume(const char *file_name, PvmVolume *v) {
 	v->scale[0] = v->scale[1] = v->scale[2] = 1.0f;
 	if (strncmp(text, "PVM\n", 4) == 0) {
 		p = text + 4;
-		while (*p == '#')                           // comment lines
-			while (*p++ != '\n') {}
+		while (p < end && *p == '#') {              // comment lines; a '#' line without a newline ends the header scan at the buffer end
+			while (p < end && *p != '\n') p++;
+			if (p < end) p++;
+		}
 		if (sscanf(p, "%u %u %u\n", &v->width, &v->height, &v->depth) != 3)
 			return false;
 	} else {
@@ -141,13 +143,13 @@ bool read_pvm_volume(const char *file_name, PvmVolume *v) {
 		if (p == NULL) return false;
 		p++;
 	}
-	if (v->width < 1 || v->height < 1 || v->depth < 1)
-		return false;
+	if (v->width < 1 || v->height < 1 || v->depth < 1 || v->width > 65535u || v->height > 65535u || v->depth > 65535u)
+		return false;                               // Model::dims is ushort3 (ModelBase.h:13); also keeps the byte count below 2^48 * components
 	p = strchr(p, '\n');
 	if (p == NULL) return false;
 	p++;
-	if (sscanf(p, "%u\n", &v->components) != 1 || v->components < 1)
-		return false;
+	if (sscanf(p, "%u\n", &v->components) != 1 || v->components < 1 || v->components > 2)
+		return false;                               // 8- or 16-bit samples only (ddsbase.cpp:475-558 quantises 2 -> 1)
 	p = strchr(p, '\n');
 	if (p == NULL) return false;
 	p++;
@@ -272,10 +274,10 @@ int ModelBase::load_model(const char *name) {
 	}
 	if (components > 2)
 		return 1;
+	if (width < 1 || height < 1 || depth < 1 || width > 65535u || height > 65535u || depth > 65535u)
+		return 1;                                   // checked BEFORE the quantiser walks width * height * depth samples
 	if (components == 2)
 		bytes = quantize_16_to_8(bytes.data(), width, height, depth);
-	if (width > 65535u || height > 65535u || depth > 65535u)
-		return 1;
 	unsigned char *copy = (unsigned char *) malloc(bytes.size());
 	if (copy == NULL)
 		return 1;

@@ -70,23 +70,29 @@ class Renderer {
 class HipRenderer : public Renderer {
 	public:
 		explicit HipRenderer(Raycaster r, int device = 0, vr_sampling sampling = VR_SAMPLE_TRILINEAR, bool device_buffer = false);
+		// several GPUs behind the same five virtuals (include/vr_hip.h vr_hip_multi_*): the frame is split into interleaved bands,
+		// gathered on devices[0]; with device_buffer the `buffer` of render_volume() is a device pointer on devices[0]
+		HipRenderer(Raycaster r, const int *devices, int n_devices, vr_sampling sampling = VR_SAMPLE_TRILINEAR, bool device_buffer = false);
 		virtual ~HipRenderer();
-		virtual const char *get_name() { return sampling_ == VR_SAMPLE_TRILINEAR ? "HIP MI355X trilinear" : "HIP MI355X nearest"; }
+		virtual const char *get_name() { return sampling_ == VR_SAMPLE_NEAREST ? "HIP MI355X nearest" : (sampling_ == VR_SAMPLE_TRILINEAR_Q8 ? "HIP MI355X trilinear q8" : "HIP MI355X trilinear"); }
 		virtual void set_window_buffer(View view);
 		virtual void set_transfer_fn(Raycaster r);
 		virtual int set_volume(Model volume);
 		virtual int render_volume(uchar4 *buffer, Raycaster r);
 
-		bool ok() const { return ctx_ != nullptr && create_status_ == 0; }
+		bool ok() const { return (ctx_ != nullptr || multi_ != nullptr) && create_status_ == 0; }
 		const char *last_error() const;
-		vr_ctx *context() { return ctx_; }
+		vr_ctx *context() { return multi_ ? vr_hip_multi_context(multi_, 0) : ctx_; }
+		vr_multi *multi() { return multi_; }
 		void set_sampling(vr_sampling s) { sampling_ = s; }
 		// fills the by-value parameter block from a Raycaster (whole-frame partition)
 		static void to_params(const Raycaster &r, vr_sampling sampling, vr_params *out);
 	private:
 		HipRenderer(const HipRenderer &);
 		HipRenderer &operator=(const HipRenderer &);
+		void prime(const Raycaster &r);
 		vr_ctx *ctx_;
+		vr_multi *multi_;
 		int create_status_;
 		vr_sampling sampling_;
 		bool device_buffer_;

@@ -3,7 +3,7 @@
 // summary table (VolR.cpp:200-223) and, for eyeballing, a PPM writer for single frames.  There is no interactive mode.
 //
 //   volr_bench [-h] [-f <file.pvm|.raw>] [-raw <w> <h> <d> [<bytes>]] [-synthetic <n>] [-dir <datasets>] [-r <id>]
-//              [-s <width> <height>] [-d <device>] [-b|-bg] [-pose <ax> <ay> <az> <dist>] [-persp] [-o <frame.ppm>]
+//              [-s <width> <height>] [-d <device>] [-devices <a,b,..>] [-b|-bg] [-pose <ax> <ay> <az> <dist>] [-persp] [-o <frame.ppm>]
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,14 +21,9 @@ namespace {
 
 const float MAX_BENCH_SAMPLE = 7500;         // VolR.cpp:26: a renderer is dropped from a configuration after a 7.5 s frame
 
-// VolR.cpp:34-38
-const char *const config_names[] = { "Interactive",
-	"Bucky", "Daisy", "VisMale", "Engine", "Foot", "Pig", "Porsche",
-	"Foot: No optims", "F: ERT on", "F: ERT+ESL on",
-	"Scale 0.9", "Scale 0.8", "Scale 0.7", "Scale 0.6", "Scale 0.5", "Scale 0.4", "Scale 0.3",
-	"Ray step *1.1", "Ray step *1.2", "Ray step *1.3", "Ray step *1.4", "Ray step *1.5", "Ray step *1.6", "Ray step *1.7" };
-
 int config = 0, device = 0, renderer_id = 1;
+std::vector<std::string> row_names = { "Interactive" };     // profiler row labels: row 0 is the interactive / single-frame row
+std::vector<int> device_list;       // -devices a,b,c: one frame split over several GPUs (vr_hip_multi_*)
 std::string dataset_dir = ".";
 unsigned synthetic_n = 0;
 std::vector<unsigned char> synthetic_voxels;
@@ -42,6 +37,7 @@ void print_usage() {
 	       "  -dir <path> : directory searched for <Name>.pvm in benchmark mode (default .)\n"
 	       "  -r <id> : renderer, 0 = HIP nearest (CPURenderer semantics), 1 = HIP trilinear (GPURenderer4 semantics)\n"
 	       "  -s <width> <height> : viewport, 128..2048 like the reference\n  -d <device> : GPU index\n"
+	       "  -devices <a,b,...> : split every frame over these GPUs (interleaved bands gathered on the first one over xGMI)\n"
 	       "  -b | -bg : benchmark mode\n  -pose <ax> <ay> <az> <dist> [-persp] -o <frame.ppm> : render one frame to a PPM file\n");
 }
 
@@ -127,72 +123,97 @@ void benchmark_config_loop() {
 			ViewBase::view.perspective = true;
 		}
 	}
-	printf("%15s,", config_names[config]);
+	printf("%15s,", row_names[config].c_str());
 	Profiler::print_avg(stdout, config);
 	config++;
 }
 
-// VolR.cpp:270-321
+// ---- the reference's configuration matrix (VolR.cpp:270-321) as DATA: one row per configuration, one loop that runs them ----
+struct BenchConfig {
+	std::string name;            // row label of the profiler table (VolR.cpp:34-38)
+	std::string dataset;         // "<name>.pvm" to load before the run; empty = keep the resident volume
+	bool foot_study;             // part of the option / scale / ray-step studies the reference runs on "Foot"
+	int esl;                     // empty-space leaping on (1) / off (0)
+	float ray_threshold;         // early-ray-termination threshold
+	float viewport_scale;        // 0 = the original viewport, else original * scale (ushort truncation, ViewBase.cpp:107-113)
+	float ray_step_factor;       // 0 = the volume's default step, else default * factor
+};
+
+std::vector<BenchConfig> build_matrix() {
+	std::vector<BenchConfig> m;
+	for (const char *ds : { "Bucky", "Daisy", "VisMale", "Engine", "Foot", "Pig", "Porsche" })
+		m.push_back({ ds, ds, false, 1, 0.95f, 0.0f, 0.0f });
+	m.push_back({ "Foot: No optims", "", true, 0, 1.0f, 0.0f, 0.0f });
+	m.push_back({ "F: ERT on", "", true, 0, 0.95f, 0.0f, 0.0f });
+	m.push_back({ "F: ERT+ESL on", "", true, 1, 0.95f, 0.0f, 0.0f });
+	// The reference steps both studies by repeated fp32 addition of 0.1 (0.9, 0.79999995, ... 0.29999992; 1.1 ... 1.7000002);
+	// the accumulated values decide the truncated viewport sizes (2048 * 0.49999991 -> 1023), so they are reproduced here.
+	float scale = 1.0f, factor = 1.0f;
+	for (int tenth = 9; tenth >= 3; tenth--) {
+		scale -= 0.1f;
+		m.push_back({ "Scale 0." + std::to_string(tenth), "", true, 1, 0.95f, scale, 0.0f });
+	}
+	for (int tenth = 1; tenth <= 7; tenth++) {
+		factor += 0.1f;
+		m.push_back({ "Ray step *1." + std::to_string(tenth), "", true, 1, 0.95f, 0.0f, factor });
+	}
+	return m;
+}
+
 void benchmark() {
 	printf("Entering benchmark loop...\n\n");
-	config = 1;
-	while (config <= 7) {
-		printf("%s benchmark\n", config_names[config]);
-		if (benchmark_load_file(config_names[config]) != 0) { config++; continue; }
-		benchmark_config_loop();
-	}
-	// the option / scale / ray-step studies run on "Foot" in the reference; a synthetic volume may stand in
-	bool have = benchmark_load_file("Foot") == 0;
-	if (!have && use_synthetic()) {
-		printf("(Foot.pvm not available: using the %u^3 synthetic shell for the remaining configurations)\n", synthetic_n);
-		have = install_volume() == 0;
-	}
-	if (!have) return;
-	printf("%s benchmark\n", config_names[config]);
-	RaycasterBase::toggle_esl();
-	RaycasterBase::change_ray_threshold(1.0f, true);
-	benchmark_config_loop();
-	printf("%s benchmark\n", config_names[config]);
-	RaycasterBase::change_ray_threshold(0.95f, true);
-	benchmark_config_loop();
-	printf("%s benchmark\n", config_names[config]);
-	RaycasterBase::toggle_esl();
-	benchmark_config_loop();
-
-	float viewport_scale = 1.0f;
+	const std::vector<BenchConfig> matrix = build_matrix();
 	const ushort2 original_size = ViewBase::view.dims;
-	while (viewport_scale > 0.3f) {
-		printf("%s benchmark\n", config_names[config]);
-		viewport_scale -= 0.1f;
-		ViewBase::set_viewport_dims(original_size, viewport_scale);
-		printf("Resolution: %dx%d\n", ViewBase::view.dims.x, ViewBase::view.dims.y);
-		benchmark_config_loop();
-	}
-	ViewBase::set_viewport_dims(original_size);
-
-	const float original_raystep = RaycasterBase::raycaster.ray_step;
-	float raystep_factor = 1.0f;
-	while (raystep_factor <= 1.7f) {
-		printf("%s benchmark\n", config_names[config]);
-		raystep_factor += 0.1f;
-		RaycasterBase::change_ray_step(original_raystep * raystep_factor, true);
+	bool foot_ready = false, foot_tried = false;
+	config = 1;
+	for (const BenchConfig &c : matrix) {
+		if (c.foot_study && !foot_tried) {                   // the studies run on "Foot"; a synthetic volume may stand in
+			foot_tried = true;
+			foot_ready = benchmark_load_file("Foot") == 0;
+			if (!foot_ready && use_synthetic()) {
+				printf("(Foot.pvm not available: using the %u^3 synthetic shell for the remaining configurations)\n", synthetic_n);
+				foot_ready = install_volume() == 0;
+			}
+		}
+		if (c.foot_study && !foot_ready) break;
+		row_names.push_back(c.name);
+		printf("%s benchmark\n", c.name.c_str());
+		if (!c.dataset.empty() && benchmark_load_file(c.dataset.c_str()) != 0) { config++; continue; }     // VolR.cpp:276-279: a missing file is skipped
+		if ((RaycasterBase::raycaster.esl ? 1 : 0) != c.esl) RaycasterBase::toggle_esl();
+		RaycasterBase::change_ray_threshold(c.ray_threshold, true);
+		if (c.ray_step_factor > 0.0f) {
+			RaycasterBase::reset_ray_step();
+			RaycasterBase::change_ray_step(RaycasterBase::raycaster.ray_step * c.ray_step_factor, true);
+		} else if (c.foot_study) {
+			RaycasterBase::reset_ray_step();
+		}
+		if (c.viewport_scale > 0.0f) {
+			ViewBase::set_viewport_dims(original_size, c.viewport_scale);
+			printf("Resolution: %dx%d\n", ViewBase::view.dims.x, ViewBase::view.dims.y);
+		} else if (ViewBase::view.dims.x != original_size.x || ViewBase::view.dims.y != original_size.y) {
+			ViewBase::set_viewport_dims(original_size);
+		}
 		benchmark_config_loop();
 	}
 	RaycasterBase::reset_ray_step();
+	ViewBase::set_viewport_dims(original_size);
 	config--;
 }
 
-// VolR.cpp:200-223 print_profiler
+// VolR.cpp:200-223: the summary table — which statistics a row shows is a property of the row
 void print_profiler() {
 	printf("\nSummary profiler report:\n");
 	for (int r = 0; r < PROFILER_RENDERERS; r++) printf(" Rend.%2i: %s\n", r, renderers[r]->get_name());
 	printf("%15s,%8s,", "Configuration", "Value");
 	for (int r = 0; r < PROFILER_RENDERERS; r++) printf(" Rend.%2i%s", r, r != PROFILER_RENDERERS - 1 ? "," : "");
 	printf("\n");
-	for (int i = 0; i <= config; i++) {
-		if (i == 0) { printf("%15s,", config_names[i]); Profiler::print_samples(stdout, i); }
-		printf("%15s,", config_names[i]); Profiler::print_avg(stdout, i);
-		if (i == 0) { printf("%15s,", config_names[i]); Profiler::print_max(stdout, i); }
+	typedef void (*Stat)(FILE *, int);
+	static const Stat interactive_stats[] = { Profiler::print_samples, Profiler::print_avg, Profiler::print_max };
+	static const Stat config_stats[] = { Profiler::print_avg };
+	for (int row = 0; row <= config && row < (int) row_names.size(); row++) {
+		const Stat *stats = row == 0 ? interactive_stats : config_stats;
+		const int count = row == 0 ? 3 : 1;
+		for (int k = 0; k < count; k++) { printf("%15s,", row_names[row].c_str()); stats[k](stdout, row); }
 	}
 }
 
@@ -247,6 +268,10 @@ int main(int argc, char **argv) {
 			ViewBase::set_viewport_dims(make_ushort2((unsigned short) w, (unsigned short) h));
 		}
 		else if (strcmp(arg, "-d") == 0) { if (need(1)) device = atoi(argv[++i]); }
+		else if (strcmp(arg, "-devices") == 0) {
+			if (!need(1)) continue;
+			for (const char *q = argv[++i]; *q; ) { device_list.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+		}
 		else if (strcmp(arg, "-bg") == 0 || strcmp(arg, "-b") == 0) benchmark_mode = true;
 		else if (strcmp(arg, "-persp") == 0) persp = true;
 		else if (strcmp(arg, "-pose") == 0) { if (need(4)) { for (int k = 0; k < 4; k++) pose[k] = (float) atof(argv[++i]); have_pose = true; } }
@@ -264,8 +289,14 @@ int main(int argc, char **argv) {
 	Profiler::init();
 
 	printf("Initializing renderers 0 - %d...\n", PROFILER_RENDERERS - 1);
-	renderers[0] = new HipRenderer(RaycasterBase::raycaster, device, VR_SAMPLE_NEAREST);
-	renderers[1] = new HipRenderer(RaycasterBase::raycaster, device, VR_SAMPLE_TRILINEAR);
+	if (!device_list.empty()) {
+		renderers[0] = new HipRenderer(RaycasterBase::raycaster, device_list.data(), (int) device_list.size(), VR_SAMPLE_NEAREST);
+		renderers[1] = new HipRenderer(RaycasterBase::raycaster, device_list.data(), (int) device_list.size(), VR_SAMPLE_TRILINEAR);
+		if (renderers[1]->ok()) printf("Frame split over %d device(s), bands gathered by %s\n", (int) device_list.size(), vr_hip_multi_transport(renderers[1]->multi()));
+	} else {
+		renderers[0] = new HipRenderer(RaycasterBase::raycaster, device, VR_SAMPLE_NEAREST);
+		renderers[1] = new HipRenderer(RaycasterBase::raycaster, device, VR_SAMPLE_TRILINEAR);
+	}
 	for (int i = 0; i < PROFILER_RENDERERS; i++)
 		if (!renderers[i]->ok()) { printf("Error: %s\n", renderers[i]->last_error()); return EXIT_FAILURE; }
 

@@ -103,6 +103,10 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 		return fail(c, VR_ERR_INVALID, "ray_step must be finite and >= 1e-6");
 	if (!std::isfinite(p->ray_threshold) || !std::isfinite(p->light_kd))
 		return fail(c, VR_ERR_INVALID, "ray_threshold / light_kd must be finite");
+	// The per-wave shortcuts for transparent samples skip the `acc.w > threshold` test, which is exact only if that test cannot
+	// newly fire at an unchanged acc.w >= 0, i.e. for threshold >= 0 (the reference's setter keeps it in [0.5, 1], RaycasterBase.cpp:31-33)
+	if (p->ray_threshold < 0.0f)
+		return fail(c, VR_ERR_INVALID, "ray_threshold must be >= 0");
 	if (p->esl && (p->esl_block_dims == 0 || p->esl_block_dims > 65535u || !finite3(p->esl_block_size)))   // unsigned short in the reference
 		return fail(c, VR_ERR_INVALID, "esl_block_dims must be in 1..65535 and esl_block_size finite when esl is on");
 	if (p->sampling != VR_SAMPLE_NEAREST && p->sampling != VR_SAMPLE_TRILINEAR && p->sampling != VR_SAMPLE_TRILINEAR_Q8)
@@ -234,6 +238,11 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		const float omax = std::fmax(std::fabs(p->view.origin[0]), std::fmax(std::fabs(p->view.origin[1]), std::fabs(p->view.origin[2])));
 		const float nmax = (float) std::max(c->dim[0], std::max(c->dim[1], c->dim[2]));
 		a.clamp_fetch = (1.0f + 2.0f * omax) * nmax < 1048576.0f ? 0u : 1u;
+		// intersect() replaces a direction component that is exactly 0 by 1e-5 (RaycasterBase.h:33-35): a ray whose origin lies
+		// up to ky * 1e-5 outside a face of the cube is then still reported as a hit and marches at that constant out-of-cube
+		// coordinate, ky * 1e-5 * N/2 texels beyond the face.  ky <= sqrt(3) * (omax + 1) for |direction| >= 1 (orthogonal: unit
+		// direction; perspective: a unit vector plus in-plane offsets).  Keep that below 1/8 texel, else clamp every sample.
+		if (1.7321f * (omax + 1.0f) * 1e-5f * nmax * 0.5f >= 0.125f) a.clamp_fetch = 1u;
 		if (c->force_clamp_fetch) a.clamp_fetch = 1u;
 	}
 	a.force_wide = c->force_wide;
@@ -290,7 +299,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 }
 
 int ready(vr_ctx *c) {
-	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "render before set_volume");
+	if (c->vol == nullptr && c->vol_bricked == nullptr) return fail(c, VR_ERR_NOT_READY, "render before set_volume");
 	if (!c->tf_set) return fail(c, VR_ERR_NOT_READY, "render before set_transfer_fn");
 	return VR_OK;
 }
@@ -306,6 +315,7 @@ int alloc_volume(vr_ctx *c, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
 	if (bpv != 1 && bpv != 2) return fail(c, VR_ERR_INVALID, "bytes_per_voxel must be 1 or 2");
 	if (c->vol) { (void) hipFree(c->vol); c->vol = nullptr; }
 	free_bricks(c);
+	c->dim[0] = c->dim[1] = c->dim[2] = 0;
 	const uint64_t elems = (uint64_t) x * y * z;
 	const uint64_t slack = volume_tail_slack(x, y);
 	VR_TRY(c, hipMalloc(&c->vol, (elems + slack) * bpv));
@@ -410,8 +420,12 @@ int vr_hip_set_transfer_fn(vr_ctx *c, const float *tf, const uint32_t *esl) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (tf == nullptr || esl == nullptr) return fail(c, VR_ERR_INVALID, "transfer_fn / esl_volume is NULL");
 	VR_TRY(c, hipSetDevice(c->device));
-	VR_TRY(c, hipMemcpy(c->tf, tf, VR_TF_SIZE * 4 * sizeof(float), hipMemcpyHostToDevice));
-	VR_TRY(c, hipMemcpy(c->esl, esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t), hipMemcpyHostToDevice));
+	// Frames queued by vr_hip_render_device run asynchronously (context stream or a caller's stream): wait for them before the
+	// tables they read are rewritten, then upload on the context stream and wait again — the reference is synchronous here too.
+	VR_TRY(c, hipDeviceSynchronize());
+	VR_TRY(c, hipMemcpyAsync(c->tf, tf, VR_TF_SIZE * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	VR_TRY(c, hipMemcpyAsync(c->esl, esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	VR_TRY(c, hipStreamSynchronize(c->stream));
 	int zero = -1;
 	while (zero + 1 < VR_TF_SIZE && tf[4 * (zero + 1)] == 0.0f && tf[4 * (zero + 1) + 1] == 0.0f && tf[4 * (zero + 1) + 2] == 0.0f &&
 	       tf[4 * (zero + 1) + 3] == 0.0f)
@@ -450,6 +464,8 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 	if (layout != VR_LAYOUT_LINEAR && layout != VR_LAYOUT_BRICKED) return fail(c, VR_ERR_INVALID, "unknown volume layout");
 	VR_TRY(c, hipSetDevice(c->device));
 	VR_TRY(c, hipDeviceSynchronize());           // a frame may still be reading the copy we are about to drop
+	if (c->vol == nullptr && c->dim[0] != 0)
+		return fail(c, VR_ERR_NOT_READY, "the linear copy was released (vr_hip_release_linear_copy): the brick copies cannot be rebuilt or dropped");
 	c->layout = layout;
 	return finalize_volume(c);
 }
@@ -532,7 +548,7 @@ int vr_hip_timing_reset(vr_ctx *c) {
 int vr_hip_volume_minmax(vr_ctx *c, uint8_t *minmax_out, uint32_t *bd_out, float *bs_out, float *kernel_ms_out) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (minmax_out == nullptr) return fail(c, VR_ERR_INVALID, "minmax_out is NULL");
-	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "minmax before set_volume");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, c->dim[0] ? "the linear copy was released (vr_hip_release_linear_copy): set the volume again" : "minmax before set_volume");
 	VR_TRY(c, hipSetDevice(c->device));
 	// RaycasterBase.cpp:97-99
 	uint32_t max_dim = c->dim[0] > c->dim[1] ? c->dim[0] : c->dim[1];
@@ -557,7 +573,7 @@ int vr_hip_volume_minmax(vr_ctx *c, uint8_t *minmax_out, uint32_t *bd_out, float
 int vr_hip_volume_histogram(vr_ctx *c, uint64_t *hist_out, float *kernel_ms_out) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (hist_out == nullptr) return fail(c, VR_ERR_INVALID, "hist_out is NULL");
-	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "histogram before set_volume");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, c->dim[0] ? "the linear copy was released (vr_hip_release_linear_copy): set the volume again" : "histogram before set_volume");
 	VR_TRY(c, hipSetDevice(c->device));
 	VR_TRY(c, hipEventRecord(c->aux_start, c->stream));
 	VR_TRY(c, launch_histogram(c->vol, c->bpv, c->vol_elems, c->hist, c->stream));
@@ -582,10 +598,39 @@ int vr_hip_generate_volume(vr_ctx *c, uint32_t kind, uint32_t n, uint32_t seed, 
 int vr_hip_download_volume(vr_ctx *c, void *host_out, uint64_t bytes) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (host_out == nullptr) return fail(c, VR_ERR_INVALID, "host_out is NULL");
-	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "download before set_volume");
+	if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, c->dim[0] ? "the linear copy was released (vr_hip_release_linear_copy): set the volume again" : "download before set_volume");
 	if (bytes != c->vol_elems * c->bpv) return fail(c, VR_ERR_INVALID, "byte count does not match the resident volume");
 	VR_TRY(c, hipSetDevice(c->device));
 	VR_TRY(c, hipMemcpy(host_out, c->vol, bytes, hipMemcpyDeviceToHost));
+	return VR_OK;
+}
+
+int vr_hip_volume_info(vr_ctx *c, vr_volume_info *out) {
+	if (c == nullptr || out == nullptr) return VR_ERR_INVALID;
+	memset(out, 0, sizeof *out);
+	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "volume_info before set_volume");
+	out->dim_x = c->dim[0]; out->dim_y = c->dim[1]; out->dim_z = c->dim[2]; out->bytes_per_voxel = c->bpv;
+	out->layout = c->vol_bricked ? VR_LAYOUT_BRICKED : VR_LAYOUT_LINEAR;
+	out->linear_resident = c->vol != nullptr ? 1u : 0u;
+	out->linear_bytes = c->vol != nullptr ? (c->vol_elems + volume_tail_slack(c->dim[0], c->dim[1])) * c->bpv : 0;
+	const uint64_t copy_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
+	for (uint32_t i = 0; i < kPlanes; i++)
+		if (c->vol_plane[i]) { out->brick_planes |= 1u << i; out->brick_copies++; out->bricked_bytes += copy_bytes; }
+	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? ((c->bpv == 1 && std::max(c->dim[0], std::max(c->dim[1], c->dim[2])) <= 1024u && copy_bytes <= (1ull << 32)) ? 3u : 1u) : 0u;
+	return VR_OK;
+}
+
+int vr_hip_release_linear_copy(vr_ctx *c) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "release_linear_copy before set_volume");
+	if (c->vol == nullptr) return VR_OK;
+	const uint32_t max_dim = std::max(c->dim[0], std::max(c->dim[1], c->dim[2]));
+	if (c->vol_bricked == nullptr || max_dim > 2048u)
+		return fail(c, VR_ERR_INVALID, "the linear array is the only copy every render path can read (linear layout, or an edge above 2048)");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, hipDeviceSynchronize());
+	(void) hipFree(c->vol);
+	c->vol = nullptr;
 	return VR_OK;
 }
 

@@ -130,9 +130,6 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
 	uint32_t w0, w1, w2, w3;
 	float xb, yb, zb;                                // texel-space coordinates of the sample (clamped in tri_resolve)
-#ifdef VR_EXP_DUP_LOADS
-	uint32_t d0, d1;                                 // measurement only: the same two loads issued a second time (L1 hits)
-#endif
 };
 
 // `clamp` (wave-uniform) = false is allowed for positions INSIDE the volume's cube, i.e. coordinates in (-1, N): there
@@ -175,34 +172,8 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 			}
 		}
 		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
-#ifdef VR_EXP_ONE_LOAD64                             // measurement only (wrong images): ONE 8-byte gather per sample
-			{
-				const uint2 both = *(const uint2 *) ((uintptr_t) q0 & ~(uintptr_t) 7);
-				f.w0 = both.x; f.w1 = both.y;
-			}
-#elif defined(VR_EXP_ONE_LOAD)                       // measurement only (wrong images): what does the second load cost?
-			f.w0 = *(const uint32_t *) q0;
-			f.w1 = f.w0;
-#elif defined(VR_EXP_ASM_LOADS)
-			if (ADDR == kAddr32) {                       // loads the compiler's waitcnt pass does not see: the ray loop waits with an exact count
-				const uint32_t o0 = (uint32_t) (q0 - (const uint8_t *) vol), o1 = (uint32_t) (q1 - (const uint8_t *) vol);
-				asm volatile("global_load_dword %0, %1, %2" : "=v"(f.w0) : "v"(o0), "s"(vol));
-				asm volatile("global_load_dword %0, %1, %2" : "=v"(f.w1) : "v"(o1), "s"(vol));
-			} else {
-				f.w0 = *(const uint32_t *) q0;
-				f.w1 = *(const uint32_t *) q1;
-			}
-#else
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
-#endif
-#ifdef VR_EXP_DUP_LOADS
-			{
-				uint64_t l0 = (uint64_t) q0, l1 = (uint64_t) q1;
-				asm volatile("" : "+v"(l0), "+v"(l1));      // opaque copies of the addresses: no CSE with the loads above
-				f.d0 = *(const uint32_t *) l0; f.d1 = *(const uint32_t *) l1;
-			}
-#endif
 		} else {                                         // 2 x global_load_dwordx2, 8-byte aligned
 			const uint2 lo = *(const uint2 *) q0, hi = *(const uint2 *) q1;
 			f.w0 = lo.x; f.w1 = lo.y; f.w2 = hi.x; f.w3 = hi.y;
@@ -293,9 +264,7 @@ __device__ __forceinline__ float rsqrt_nr(float x) {
 	const float h = 0.5f * x;
 	y = y * VR_FMA(-(h * y), y, 1.5f);
 	y = y * VR_FMA(-(h * y), y, 1.5f);
-#ifndef VR_EXP_RSQRT2
 	y = y * VR_FMA(-(h * y), y, 1.5f);
-#endif
 	return y;
 }
 
@@ -645,7 +614,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #if VR_PREFETCH_DEPTH == 2
 			float k1 = kx + step;                                  // k of the sample after the current one
 #endif
-			auto step_sample = [&](TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
+			auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
 #if VR_PREFETCH_DEPTH == 2
 				const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
 				const float k2 = k1 + step;
@@ -665,14 +634,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
 				//      follows: the wave skips unpacking, the 7 lerps and everything after them;
 				//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
-#ifdef VR_EXP_DUP_LOADS
-				if (LAYOUT == kLayoutBricked && BPV == 1) asm volatile("" :: "v"(cur.d0), "v"(cur.d1));
-#endif
-#ifdef VR_EXP_ASM_LOADS
-				// the two gathers of `cur` are followed by those of the two younger slots (4 loads); any load of a shading block in
-				// between was waited for by the compiler itself
-				if (LAYOUT == kLayoutBricked && BPV == 1 && ADDR == kAddr32) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur.w0), "+v"(cur.w1));
-#endif
 				uint32_t corners;
 				if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
 				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
@@ -697,9 +658,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 						const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
 						TriFetch<BPV, LAYOUT> lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
 						                                                        VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb), true);
-#ifdef VR_EXP_ASM_LOADS
-						if (LAYOUT == kLayoutBricked && BPV == 1 && ADDR == kAddr32) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lf.w0), "+v"(lf.w1));
-#endif
 						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a);
 						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 						c.x += diffuse; c.y += diffuse; c.z += diffuse;

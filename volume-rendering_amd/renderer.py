@@ -130,9 +130,87 @@ class HipRenderer:
         self._check(self._L.vr_hip_volume_histogram(self._ctx, h.ctypes.data, C.byref(ms)), "volume_histogram")
         return h, float(ms.value)
 
+    def volume_info(self):
+        """vr_volume_info: what the resident volume occupies (how many brick copies were actually built, linear array present)."""
+        from .binding import VrVolumeInfo
+        info = VrVolumeInfo()
+        self._check(self._L.vr_hip_volume_info(self._ctx, C.byref(info)), "volume_info")
+        return info
+
+    def release_linear_copy(self):
+        """Frees the linear array (feeders / download / layout changes then need a new set_volume); rendering is unaffected."""
+        self._check(self._L.vr_hip_release_linear_copy(self._ctx), "release_linear_copy")
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus = C.c_uint32()
         mem = C.c_uint64()
         self._check(self._L.vr_hip_device_info(self._ctx, name, 256, C.byref(cus), C.byref(mem)), "device_info")
         return name.value.decode(), int(cus.value), int(mem.value)
+
+
+class MultiRenderer:
+    """Several GPUs of ONE process behind one render call (vr_hip_multi_* of include/vr_hip.h): interleaved bands per device,
+    gathered on devices[0] over xGMI (RCCL send/recv, or peer copies), de-interleaved there.  `params` describe the whole frame."""
+
+    def __init__(self, devices):
+        self._L = lib()
+        self._m = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._L.vr_hip_multi_create(len(devices), devs, C.byref(self._m))
+        if rc:
+            msg = self._L.vr_hip_multi_last_error(self._m).decode() if self._m else "no usable HIP device; there is no CPU fallback"
+            if self._m:
+                self._L.vr_hip_multi_destroy(self._m)
+                self._m = C.c_void_p()
+            raise VrError(rc, msg)
+        self.devices = list(devices)
+
+    def close(self):
+        if self._m:
+            self._L.vr_hip_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc:
+            raise VrError(rc, f"{what}: {self._L.vr_hip_multi_last_error(self._m).decode()}")
+
+    @property
+    def transport(self):
+        return self._L.vr_hip_multi_transport(self._m).decode()
+
+    def set_window_buffer(self, width, height):
+        self._check(self._L.vr_hip_multi_set_window(self._m, width, height), "set_window_buffer")
+
+    def set_transfer_fn(self, tf_premult, esl_bits):
+        tf = np.ascontiguousarray(tf_premult, dtype=np.float32)
+        esl = np.ascontiguousarray(esl_bits, dtype=np.uint32)
+        self._check(self._L.vr_hip_multi_set_transfer_fn(self._m, tf.ctypes.data, esl.ctypes.data), "set_transfer_fn")
+
+    def set_volume(self, voxels):
+        v = np.ascontiguousarray(voxels)
+        z, y, x = v.shape
+        self._check(self._L.vr_hip_multi_set_volume(self._m, v.ctypes.data, x, y, z, v.dtype.itemsize), "set_volume")
+
+    def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
+        self._check(self._L.vr_hip_multi_generate_volume(self._m, {"shell": 0, "noise": 1}[kind], n, seed, bytes_per_voxel), "generate_volume")
+
+    def render_volume(self, params):
+        out = np.empty((params.view.height, params.view.width, 4), dtype=np.uint8)
+        self._check(self._L.vr_hip_multi_render(self._m, C.byref(params), out.ctypes.data), "render_volume")
+        return out
+
+    def render_volume_device(self, params, dev_ptr):
+        self._check(self._L.vr_hip_multi_render_device(self._m, C.byref(params), C.c_void_p(dev_ptr)), "render_volume_device")
+
+    def timing(self):
+        per = (C.c_float * len(self.devices))()
+        total = C.c_float()
+        self._check(self._L.vr_hip_multi_timing(self._m, per, C.byref(total)), "timing")
+        return [float(x) for x in per], float(total.value)
