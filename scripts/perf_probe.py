@@ -42,7 +42,7 @@ def main():
         scene.set_modes(esl=False, ray_threshold=1.0)
     scene.set_modes(light_kd=a.light)
     r.set_transfer_fn(scene.tf, scene.esl)
-    samp = vr.SAMPLE_TRILINEAR if a.sampling == "trilinear" else vr.SAMPLE_NEAREST
+    samp = {"trilinear": vr.SAMPLE_TRILINEAR, "q8": vr.SAMPLE_TRILINEAR_Q8}.get(a.sampling, vr.SAMPLE_NEAREST)
     buf = torch.empty((W, W, 4), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     res = {}

@@ -45,7 +45,7 @@ class VrParams(C.Structure):
 class VrVolumeInfo(C.Structure):
     _fields_ = [("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("dim_z", C.c_uint32), ("bytes_per_voxel", C.c_uint32),
                 ("layout", C.c_uint32), ("brick_copies", C.c_uint32), ("brick_copies_wanted", C.c_uint32), ("brick_planes", C.c_uint32),
-                ("linear_resident", C.c_uint32), ("reserved", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64)]
+                ("linear_resident", C.c_uint32), ("run_copy", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64)]
 
 
 class VrTiming(C.Structure):

@@ -53,7 +53,22 @@ struct RayKernelArgs {
 //                   quad's four addresses share an aligned 16-byte chunk (scripts/ubench/tcp_coalesce.hip), which is
 //                   what the brick order and the lane order of the ray-march kernel are chosen for.  Costs 4x the voxel
 //                   bytes in HBM.
-enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1 };
+//   kLayoutRun    : "run bricks" — the same quad elements, but the 8 elements of a cell column (x,y) inside a brick are
+//                   CONTIGUOUS along z and followed by a duplicate of the next brick's first one (9 x 4 = 36 bytes), so that the
+//                   slices z and z+1 of ANY sample are 8 adjacent bytes: ONE global_load_dwordx2 (4-byte aligned) per sample.
+//                   Measured (scripts/ubench/tcp_gather64.hip): for lane quads that straddle chunks — every view that is not
+//                   along a volume axis — one such gather costs 8-9 ns per wave against 2 x 7-9 ns for the two 4-byte gathers;
+//                   for the chunk-aligned quads of axis-aligned views the two 4-byte gathers are cheaper (2 x 1.9 ns against
+//                   6.8), so this copy is read by oblique views only.  9/8 of a quad copy, 64-bit addresses (4.5 GiB at 1024^3).
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2 };
+constexpr uint32_t kRunLen = 9, kRunBytes = kRunLen * 4, kRunBrickBytes = 64 * kRunBytes;       // 8x8 cell columns per brick
+// byte offset of cell column (x & 7, y & 7) inside a run brick: 2-D Morton order, 36-byte runs
+__host__ __device__ inline uint32_t run_cell_spread(uint32_t axis, uint32_t v) {
+	return (((v & 1u) << axis) | (((v >> 1) & 1u) << (2 + axis)) | (((v >> 2) & 1u) << (4 + axis))) * kRunBytes;
+}
+inline uint64_t run_copy_bytes(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
+	return (uint64_t) ((dim_x + 7) / 8) * ((dim_y + 7) / 8) * ((dim_z + 7) / 8) * kRunBrickBytes + 16;
+}
 enum : uint32_t { kLaneRows = 0, kLaneColumns = 1, kLaneBlocks = 2 };
 constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 
@@ -92,13 +107,16 @@ inline uint64_t volume_tail_slack(uint32_t dim_x, uint32_t dim_y) { return (uint
 // linear -> quad-brick copy
 hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per_voxel, uint32_t plane, uint32_t dim_x, uint32_t dim_y,
                            uint32_t dim_z, hipStream_t stream);
+// linear -> run bricks (1-byte voxels)
+hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 // number of quad elements (each 4 * bytes_per_voxel bytes)
 inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 	return (uint64_t) ((dim_x + kBrickEdge - 1) / kBrickEdge) * ((dim_y + kBrickEdge - 1) / kBrickEdge) *
 	       ((dim_z + kBrickEdge - 1) / kBrickEdge) * kBrickPitch;
 }
 
-// `linear` is the reference's array (always resident); `bricked` the quad-brick copy or NULL (VR_LAYOUT_LINEAR).
+// `linear` is the reference's array; `bricked` the brick copy RayKernelArgs::layout names (quad bricks of plane
+// brick_plane, or the run bricks) or NULL (VR_LAYOUT_LINEAR).
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bytes_per_voxel,
                            const float *tf_premult /* 128 x float4 */, const uint32_t *esl_bits /* 1024 */,
                            void *out_rgba, hipStream_t stream);

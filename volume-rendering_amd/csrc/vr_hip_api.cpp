@@ -41,14 +41,16 @@ struct vr_ctx {
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
 	void *vol_bricked = nullptr;            // brick copy with chunk plane (x,y) (vr_device.h), built by set_volume
 	void *vol_plane[kPlanes] = { nullptr, nullptr, nullptr };   // [0] = vol_bricked; [1], [2]: chunk planes (x,z), (y,z) — u8, edges <= 1024
-	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis), else forced (testing)
+	void *vol_run = nullptr;                // run bricks (vr_device.h kLayoutRun): one 8-byte gather per sample, read by oblique views
+	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
+	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
 	uint32_t layout = VR_LAYOUT_BRICKED;
 	uint32_t force_wide = 0;
 	uint32_t force_clamp_fetch = 0;              // testing aid (vr_hip_set_wide_addressing bit 2)
 	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
 	uint32_t tile_phase_x = 0, tile_phase_y = 0;
 	// the last few automatic choices, keyed by the frame parameters and the volume size (a benchmark cycles 8 views)
-	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y; };
+	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
@@ -127,7 +129,9 @@ int validate_params(vr_ctx *c, const vr_params *p) {
 //  * any other view keeps 4x1-pixel quads, along the screen axis whose image in the volume stays closest to the x/y plane;
 //  * orthogonal views also shift the tile grid by 0..3 pixels so that 4-pixel groups start on even cells (when the pixel
 //    pitch is commensurate with the voxel grid — the reference's default zoom — every quad then reads a single chunk).
-void choose_tile_mapping(RayKernelArgs &a) {
+// Returns, for orthogonal views, how many of the sampled 4-pixel groups still straddle cells under the best phase (per mille);
+// 1000 for views whose quads cannot be aligned at all (perspective, or not along an axis).
+uint32_t choose_tile_mapping(RayKernelArgs &a) {
 	const vr_view &v = a.p.view;
 	// voxel-cell coordinate of a position p: TRILINEAR p * N/2 + N/2 - 1/2 (texel space), NEAREST (p + 1) / 2 * N (ModelBase.h:17-23)
 	const bool nearest = a.p.sampling == VR_SAMPLE_NEAREST;
@@ -139,7 +143,7 @@ void choose_tile_mapping(RayKernelArgs &a) {
 	auto major = [](const float *u) { int m = 0; for (int i = 1; i < 3; i++) if (std::fabs(u[i]) > std::fabs(u[m])) m = i; return m; };
 	a.lane_map = kLaneRows; a.phase_x = a.phase_y = 0;
 	const float dn = norm(d);
-	if (!(dn > 0.0f)) return;
+	if (!(dn > 0.0f)) return 1000u;
 	if (std::fabs(d[major(d)]) > 0.98f * dn) a.lane_map = kLaneBlocks;
 	else {
 		// 4x1-pixel quads along the screen axis that leaves the chunk plane least: `out` is the axis not in the plane
@@ -148,7 +152,8 @@ void choose_tile_mapping(RayKernelArgs &a) {
 		const float nx = norm(sx), ny = norm(sy);
 		if (nx > 0.0f && ny > 0.0f && std::fabs(sy[out]) * nx < std::fabs(sx[out]) * ny) a.lane_map = kLaneColumns;
 	}
-	if (v.perspective) return;
+	if (v.perspective) return 1000u;
+	const bool axis_aligned = a.lane_map == kLaneBlocks;
 	// orthogonal view: every ray has the same direction; [k_in, k_out] = the central ray's path through the cube
 	float k_in = -1e30f, k_out = 1e30f;
 	for (int i = 0; i < 3; i++) {
@@ -156,7 +161,7 @@ void choose_tile_mapping(RayKernelArgs &a) {
 		const float k1 = (-1.0f - v.origin[i]) / v.direction[i], k2 = (1.0f - v.origin[i]) / v.direction[i];
 		k_in = std::fmax(k_in, std::fmin(k1, k2)); k_out = std::fmin(k_out, std::fmax(k1, k2));
 	}
-	if (!(k_in < k_out) || !(k_out < 1e29f)) return;
+	if (!(k_in < k_out) || !(k_out < 1e29f)) return 1000u;
 	k_in = std::fmax(k_in, 0.0f);
 	// Voxel cell of frame pixel (gx, gy) at depth k along volume axis `ax`, with the KERNEL'S OWN fp32 operations (get_ray,
 	// then fma(k, A, B) / (pos + 1) * half): pixels of an axis-aligned view at the reference's default zoom sit exactly on
@@ -176,13 +181,14 @@ void choose_tile_mapping(RayKernelArgs &a) {
 	// edges that are not 4-cell (128-byte line) boundaries — a wave whose 4x4 cells sit inside one line column touches a
 	// quarter of the lines, and workgroup footprints that end on line boundaries do not fetch their border lines twice
 	// (measured before: 2.0x the compulsory bytes at L2 with 4-pixel alignment only).
+	long groups_seen = 0, groups_straddling = 0;          // of the winning phases, both screen directions
 	auto best_phase = [&](bool horizontal, uint32_t first, uint32_t count, uint32_t other_centre) {
 		const float *sdir = horizontal ? sx : sy;
 		const int ax = major(sdir);
 		const long hi = (long) (2.0f * half[ax]) - 1;
-		uint32_t best = 0; long best_cost = -1;
+		uint32_t best = 0; long best_cost = -1, best_seen = 0, best_bad = 0;
 		for (uint32_t ph = 0; ph < 8; ph++) {
-			long cost = 0;
+			long cost = 0, seen = 0, bad = 0;
 			for (int depth = 0; depth < 4; depth++) {
 				const float k = k_in + (k_out - k_in) * (0.125f + 0.25f * (float) depth);
 				for (long g0 = -(long) ph; g0 < (long) count; g0 += 8 * 7) {      // every seventh wave column is plenty
@@ -193,21 +199,26 @@ void choose_tile_mapping(RayKernelArgs &a) {
 						in[i] = g0 + i >= 0 && g0 + i < (long) count && cell[i] >= 0 && cell[i] <= hi;
 					}
 					for (int q = 0; q < 8; q += 4) {
+						const long before = cost;
 						if (in[q] && in[q + 3] && (cell[q] >> 1) != (cell[q + 3] >> 1)) cost += 32;          // the group leaves its aligned cell pair
 						if (in[q] && in[q + 1] && cell[q] != cell[q + 1]) cost += 16;                        // a pixel pair straddles two cells
 						if (in[q + 2] && in[q + 3] && cell[q + 2] != cell[q + 3]) cost += 16;
+						if (in[q] && in[q + 3]) { seen++; if (cost != before) bad++; }
 					}
 					if (in[0] && in[7] && (cell[0] >> 2) != (cell[7] >> 2)) cost += 1;                       // the wave leaves its line column
 				}
 			}
-			if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ph; }
+			if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ph; best_seen = seen; best_bad = bad; }
 		}
+		groups_seen += best_seen; groups_straddling += best_bad;
 		return best;
 	};
 	// rows: local row ly maps to frame row gy; with bands of a multiple of 8 rows (or one band) gy = ly + const (mod 8)
 	const uint32_t gy0 = a.p.band_first * a.p.band_rows;
 	a.phase_x = best_phase(true, a.p.x0, a.p.out_width, gy0 + std::min(a.p.out_rows, a.p.band_rows) / 2u);
 	a.phase_y = best_phase(false, gy0, a.p.out_rows < a.p.band_rows ? a.p.out_rows : a.p.band_rows, a.p.x0 + a.p.out_width / 2u);
+	if (!axis_aligned || groups_seen == 0) return 1000u;
+	return (uint32_t) (groups_straddling * 1000 / groups_seen);
 }
 
 int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
@@ -247,6 +258,8 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 	a.force_wide = c->force_wide;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
+	const void *brick_copy = nullptr;
+	bool run_candidate = false, run_if_unaligned = false;
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
 	a.brick_plane = kPlaneXY;
@@ -259,10 +272,21 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			const float dx = std::fabs(p->view.direction[0] * a.half_x), dy = std::fabs(p->view.direction[1] * a.half_y),
 			            dz = std::fabs(p->view.direction[2] * a.half_z);
 			const float dmax = std::fmax(dx, std::fmax(dy, dz));
-			if (dmax > 0.98f * std::sqrt(dx * dx + dy * dy + dz * dz))
+			if (dmax > 0.98f * std::sqrt(dx * dx + dy * dy + dz * dz)) {
 				plane = dz >= dx && dz >= dy ? kPlaneXY : (dy >= dx ? kPlaneXZ : kPlaneYZ);
+				// Perspective along x or y: the pixel pitch grows from 0.4 to 1.1 cells along the march, most lane quads straddle
+				// chunks, and the run bricks — whose runs (along z) then lie across the march — are faster (measured 2.08 / 2.18 ms
+				// against 2.49 / 2.51 ms on the benchmark poses).  Along z the runs lie along the march and the quad copy wins
+				// (2.48 against 2.99 ms).  Orthogonal views along an axis are decided below, from how well their quads can be aligned.
+				if (p->view.perspective && plane != kPlaneXY) run_candidate = true;
+				else if (!p->view.perspective) run_if_unaligned = true;
+			} else {
+				run_candidate = true;       // not along an axis: lane quads straddle chunks whatever the plane -> one 8-byte gather
+			}
 		}
 		if (plane < kPlanes && c->vol_plane[plane]) a.brick_plane = plane;
+		else if (plane == kPlanes && c->vol_run) a.layout = kLayoutRun;
+		if (run_candidate && c->vol_run) a.layout = kLayoutRun;
 	}
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
@@ -278,21 +302,28 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		for (uint32_t i = 0; i < c->map_cached && hit == nullptr; i++)
 			if (memcmp(&c->map_cache[i].p, p, sizeof *p) == 0 && memcmp(c->map_cache[i].dim, c->dim, sizeof c->dim) == 0) hit = &c->map_cache[i];
 		if (hit == nullptr) {
-			choose_tile_mapping(a);
+			const uint32_t straddle = choose_tile_mapping(a);
 			hit = &c->map_cache[c->map_next];
+			hit->straddle_permille = straddle;
 			c->map_next = (c->map_next + 1) % 16u;
 			if (c->map_cached < 16u) c->map_cached++;
 			hit->p = *p; memcpy(hit->dim, c->dim, sizeof c->dim);
 			hit->lane_map = a.lane_map; hit->phase_x = a.phase_x; hit->phase_y = a.phase_y;
 		}
 		a.lane_map = hit->lane_map; a.phase_x = hit->phase_x; a.phase_y = hit->phase_y;
+		// An orthogonal view along an axis whose pixels sit exactly on cell boundaries can carry rounding noise in its direction
+		// (pose (180,90,0): components of 4e-8) that moves boundary pixels to the other neighbour part-way along the ray and
+		// differently across the frame: no phase aligns it.  Measured on that pose: 3.18 ms with the run bricks against 3.71 ms.
+		if (run_if_unaligned && c->vol_run && hit->straddle_permille > 150u) a.layout = kLayoutRun;
 	}
+	if (a.layout == kLayoutRun) brick_copy = c->vol_run;
+	else if (a.layout == kLayoutBricked) brick_copy = c->vol_plane[a.brick_plane];
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
 	VR_TRY(c, hipEventRecord(ev.start, stream));
-	VR_TRY(c, launch_raymarch(a, c->vol, a.layout == kLayoutBricked ? c->vol_plane[a.brick_plane] : nullptr, c->bpv, c->tf, c->esl, dev_rgba, stream));
+	VR_TRY(c, launch_raymarch(a, c->vol, brick_copy, c->bpv, c->tf, c->esl, dev_rgba, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
 	return VR_OK;
@@ -306,6 +337,7 @@ int ready(vr_ctx *c) {
 
 void free_bricks(vr_ctx *c) {
 	for (uint32_t i = 0; i < kPlanes; i++) if (c->vol_plane[i]) { (void) hipFree(c->vol_plane[i]); c->vol_plane[i] = nullptr; }
+	if (c->vol_run) { (void) hipFree(c->vol_run); c->vol_run = nullptr; }
 	c->vol_bricked = nullptr;
 }
 
@@ -341,6 +373,15 @@ int finalize_volume(vr_ctx *c) {
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) break;
 		if (hipMalloc(&c->vol_plane[plane], bytes) != hipSuccess) { c->vol_plane[plane] = nullptr; (void) hipGetLastError(); break; }
 		VR_TRY(c, launch_brickify(c->vol, c->vol_plane[plane], c->bpv, plane, c->dim[0], c->dim[1], c->dim[2], c->stream));
+	}
+	// the run bricks for views that are not along an axis: same conditions (1-byte voxels, table-addressable edges, spare HBM)
+	if (c->bpv == 1 && max_dim <= 1024u) {
+		const uint64_t run_bytes = run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && run_bytes < free_b && free_b - run_bytes >= total_b / 2) {
+			if (hipMalloc(&c->vol_run, run_bytes) != hipSuccess) { c->vol_run = nullptr; (void) hipGetLastError(); }
+			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run, c->dim[0], c->dim[1], c->dim[2], c->stream));
+		}
 	}
 	VR_TRY(c, hipStreamSynchronize(c->stream));
 	return VR_OK;
@@ -479,7 +520,7 @@ int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 
 int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	if (plane < -1 || plane >= (int32_t) kPlanes) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z) or 2 (y,z)");
+	if (plane < -1 || plane > (int32_t) kPlanes) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z) or 3 (run bricks)");
 	c->brick_plane_force = plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane
 	return VR_OK;
@@ -616,6 +657,7 @@ int vr_hip_volume_info(vr_ctx *c, vr_volume_info *out) {
 	const uint64_t copy_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
 	for (uint32_t i = 0; i < kPlanes; i++)
 		if (c->vol_plane[i]) { out->brick_planes |= 1u << i; out->brick_copies++; out->bricked_bytes += copy_bytes; }
+	if (c->vol_run) { out->run_copy = 1u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
 	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? ((c->bpv == 1 && std::max(c->dim[0], std::max(c->dim[1], c->dim[2])) <= 1024u && copy_bytes <= (1ull << 32)) ? 3u : 1u) : 0u;
 	return VR_OK;
 }

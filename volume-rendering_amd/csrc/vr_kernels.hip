@@ -148,7 +148,15 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 	}
 	const uint32_t ix = (uint32_t) (int) xb, iy = (uint32_t) (int) yb, iz = (uint32_t) (int) zb;
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
-	if (LAYOUT == kLayoutBricked) {
+	if (LAYOUT == kLayoutRun) {
+		// run bricks: x / y tables hold the cell column's offset, the z table the ABSOLUTE 64-bit address of (brick slab, z & 7);
+		// slices z and z+1 are 8 adjacent bytes (the ninth element of a run duplicates the next brick's first)
+		typedef LutCfg<kAddr32> L;
+		const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
+		const uint2 zz = *(const uint2 *) (lut + 2 * iz);
+		const uint2 both = *(const uint2 *) ((((uint64_t) zz.y) << 32 | zz.x) + exy);        // global_load_dwordx2, 4-byte aligned
+		f.w0 = both.x; f.w1 = both.y;
+	} else if (LAYOUT == kLayoutBricked) {
 		constexpr uint32_t kElem = 4 * BPV;
 		const uint8_t *q0, *q1;
 		if (ADDR == kAddrWide) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, con
 	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.yb, 0.0f, a.max_y)));
 	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.zb, 0.0f, a.max_z)));
 	float v000, v100, v010, v110, v001, v101, v011, v111;
-	if (LAYOUT == kLayoutBricked) {
+	if (LAYOUT != kLayoutLinear) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
 			v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v010 = (float) ((f.w0 >> 16) & 0xffu); v110 = (float) (f.w0 >> 24);
 			v001 = (float) (f.w1 & 0xffu); v101 = (float) ((f.w1 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
@@ -347,10 +355,10 @@ __device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
-__global__ __launch_bounds__(LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)>::threads)
+__global__ __launch_bounds__(LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)>::threads)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
                      const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
-	typedef LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)> L;
+	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
 	constexpr bool kUseLut = L::max_dim != 0;
 	constexpr uint32_t kThreads = L::threads;
@@ -364,7 +372,16 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
 		const uint32_t t = threadIdx.x;
-		if (kUseLut) {
+		if (kUseLut && LAYOUT == kLayoutRun) {
+			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
+			const uint64_t slab = (uint64_t) a.nbx * a.nby * kRunBrickBytes;                  // bricks: x fastest, then y, then z
+			for (uint32_t i = t; i < nz; i += kThreads) {
+				const uint64_t z0 = (uint64_t) (uintptr_t) vol + (i >> 3) * slab + (i & 7u) * 4u;
+				lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) (z0 >> 32);
+			}
+			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = (i >> 3) * kRunBrickBytes + run_cell_spread(0, i & 7u);
+			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u);
+		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
 			const uint32_t elem = 4u * BPV;                                  // bytes per quad element
 			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
@@ -635,7 +652,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				//      follows: the wave skips unpacking, the 7 lerps and everything after them;
 				//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
 				uint32_t corners;
-				if (LAYOUT == kLayoutBricked) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
+				if (LAYOUT != kLayoutLinear) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
 				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
 				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(cur, a);                                    // GPURenderer4.cu:76
@@ -706,7 +723,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
 static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, const float *tf, const uint32_t *esl,
                                  void *out, hipStream_t stream) {
-	constexpr uint32_t threads = LutCfg<(LAYOUT == kLayoutBricked ? ADDR : kAddrWide)>::threads;
+	constexpr uint32_t threads = LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)>::threads;
 	RayKernelArgs a = args;
 	a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
 	a.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
@@ -720,6 +737,10 @@ static hipError_t launch_sampling(const RayKernelArgs &a, const void *linear, co
                                   const uint32_t *esl, void *out, hipStream_t stream) {
 	constexpr bool nearest = SAMPLING == VR_SAMPLE_NEAREST;
 	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
+	if constexpr (!nearest && BPV == 1) {
+		if (bricked != nullptr && a.layout == kLayoutRun)
+			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRun>(a, bricked, tf, esl, out, stream);
+	}
 	if (bricked != nullptr) {
 		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
 		if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
@@ -785,6 +806,40 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint
 	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
 	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	return hipGetLastError();
+}
+
+// linear -> run bricks: one thread per stored element; element k = 8 of a run is the first element of the brick above
+// (slice index clamped at the top face, where the interpolation weight is exactly 0)
+__global__ __launch_bounds__(256)
+void brickify_run_kernel(const uint8_t *__restrict__ lin, uint8_t *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                         uint32_t nbx, uint32_t nby, uint32_t nbz) {
+	const uint64_t total = (uint64_t) nbx * nby * nbz * 64u * kRunLen;
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+		const uint64_t brick = o / (64u * kRunLen);
+		const uint32_t in = (uint32_t) (o - brick * (64u * kRunLen)), cell = in / kRunLen, k = in - cell * kRunLen;
+		const uint32_t lx = (cell & 1u) | ((cell >> 1) & 2u) | ((cell >> 2) & 4u), ly = ((cell >> 1) & 1u) | ((cell >> 2) & 2u) | ((cell >> 3) & 4u);
+		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
+		const uint32_t by = br / nbx, bx = br - by * nbx;
+		const uint32_t x = bx * 8u + lx, y = by * 8u + ly;
+		uint32_t z = bz * 8u + k;
+		uint8_t q[4] = { 0, 0, 0, 0 };
+		if (x < dim_x && y < dim_y && bz * 8u < dim_z) {
+			if (z > dim_z - 1) z = dim_z - 1;
+			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1;
+			const uint8_t *slice = lin + (uint64_t) z * dim_y * dim_x;
+			q[0] = slice[(uint64_t) y * dim_x + x];  q[1] = slice[(uint64_t) y * dim_x + x1];
+			q[2] = slice[(uint64_t) y1 * dim_x + x]; q[3] = slice[(uint64_t) y1 * dim_x + x1];
+		}
+		uint8_t *dst = out + o * 4;
+		dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+	}
+}
+
+hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+	const uint32_t nbx = (dim_x + 7) / 8, nby = (dim_y + 7) / 8, nbz = (dim_z + 7) / 8;
+	hipLaunchKernelGGL(brickify_run_kernel, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	return hipGetLastError();
 }
 
