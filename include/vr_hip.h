@@ -134,7 +134,8 @@ int vr_hip_set_layout(vr_ctx *ctx, uint32_t layout);
 /* Testing aid: makes every later frame use one of the two 64-bit addressing paths that volumes beyond 1024^3 / 4 GiB need
  * (BASELINE config 5), so that they can be parity-tested on small volumes: 1 = index arithmetic without tables (dims above
  * 2048), 2 = address tables with 64-bit z offsets (dims up to 2048), 0 = automatic; + 4 = clamp the fetch coordinates of
- * every TRILINEAR sample, which only views very far from the volume need.  Images are identical either way. */
+ * every sample, which only views very far from the volume or very long ray steps need; + 8 = NEAREST does not use the
+ * scaled-domain address chain that volumes with power-of-two edges get.  Images are identical either way. */
 int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
 
 /* Which of the up to three brick copies the TRILINEAR fetch reads — they differ in the plane, (x,y) / (x,z) / (y,z), that the

@@ -42,6 +42,21 @@ def test_nearest_bit_exact_vs_reference_frames(vr, gpu, golden):
         assert ndiff == 0, f"{case['label']}: {ndiff} pixels differ, max delta {maxd}"
 
 
+def test_nearest_address_chain_variants_agree(vr, gpu, golden):
+    """Bucky is 32^3 (power-of-two edges): NEAREST marches in the scaled domain by default; + 8 switches that off, + 4 clamps every
+    fetch coordinate.  All three are the reference's frame, bit for bit."""
+    gpu.set_window_buffer(256, 256)
+    load_volume(gpu, golden, "bucky")
+    try:
+        for case in [c for c in golden.cases(True) if c["volume"] == "bucky"][::3]:
+            for force in (0, 8, 4, 12):
+                gpu.set_wide_addressing(force)
+                out = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+                assert compare_frames(out, golden.frame(case)) == (0, 0), (case["label"], force)
+    finally:
+        gpu.set_wide_addressing(False)
+
+
 def test_config2_shell256_hashes(vr, gpu, golden):
     """BASELINE config 2: shell 256^3 generated on the GPU, 1024x1024, ortho poses 0/1, default and no-optims."""
     gpu.generate_volume("shell", 256, seed=1)

@@ -13,6 +13,17 @@ namespace vr {
 // is cut off instead of stalling the GPU (k += ray_step stops advancing once k >= 2^24 * ray_step).
 constexpr uint32_t kMaxRaySteps = 1u << 22;
 
+// Software pipeline of the march: the gathers of sample i + kDepth are issued before sample i is consumed; the loop body is
+// instantiated once per fetch slot (kDepth + 1 of them, rotating roles — no register copies) and iteration.  A finished lane has
+// up to kDepth speculative fetches beyond its exit point, which the kLutPad repeated edge entries of the address tables absorb:
+// the host checks kDepth * (cells per step) + 1.5 <= kLutPad per frame and otherwise runs the coordinate-clamping variant.
+#ifndef VR_DEPTH
+#define VR_DEPTH 4
+#endif
+constexpr int kDepth = VR_DEPTH, kSlots = kDepth + 1;
+constexpr int kLutPad = 10;
+static_assert(kDepth >= 1 && kDepth <= 6, "prefetch depth");
+
 // Everything the ray-march kernel reads that is not an array: passed BY VALUE as the kernel argument (the reference
 // does the same with its Raycaster POD, GPURenderer1.cu:30,108) so it lands in SGPRs via s_load from the kernarg segment.
 struct RayKernelArgs {
@@ -33,7 +44,9 @@ struct RayKernelArgs {
 	uint32_t skip_mask;                // per-voxel bit mask ~(skip_below - 1), replicated over the packed word: all 8 corners below the
 	                                   // power of two skip_below => TF coordinate <= tf_zero_below
 	uint32_t skip_never;               // 1 when the TF has no leading zero entries (the corner test must always fail), else 0
-	uint32_t clamp_fetch;              // 1: clamp the fetch coordinates of every sample (views whose fp32 coordinates may leave (-1, N))
+	uint32_t clamp_fetch;              // 1: clamp the fetch coordinates of every sample (views whose fp32 coordinates may leave (-1, N),
+	                                   // ray steps so long that two of them leave the table padding)
+	uint32_t near_scaled;              // 1: every edge is a power of two — NEAREST may march in the scaled domain (sample_nearest_scaled)
 	uint32_t esl_div_magic, esl_div_shift;   // n / esl_block_dims: magic != 0 ? mulhi(n, magic) : n >> shift
 	uint32_t layout;                   // vr_layout in use for this launch
 	uint32_t brick_plane;              // chunk plane of the brick copy handed to the kernel (kPlaneXY ...)

@@ -254,7 +254,24 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		// coordinate, ky * 1e-5 * N/2 texels beyond the face.  ky <= sqrt(3) * (omax + 1) for |direction| >= 1 (orthogonal: unit
 		// direction; perspective: a unit vector plus in-plane offsets).  Keep that below 1/8 texel, else clamp every sample.
 		if (1.7321f * (omax + 1.0f) * 1e-5f * nmax * 0.5f >= 0.125f) a.clamp_fetch = 1u;
-		if (c->force_clamp_fetch) a.clamp_fetch = 1u;
+		// The unclamped march fetches up to kDepth steps past a ray's exit point (software pipeline): that must stay inside the
+		// kLutPad repeated edge entries of the address tables.  The reference's longest step is 1.666 cells (RaycasterBase.cpp:90).
+		// A step moves a ray by ray_step * |direction component| * N/2 cells along an axis; perspective directions are not
+		// normalised (direction + right * fx + up * fy, ViewBase.h:29-31), so the bound is taken over the whole frame.
+		{
+			const float half[3] = { a.half_x, a.half_y, a.half_z };
+			float advance = 0.0f;
+			for (int i = 0; i < 3; i++) {
+				float d = std::fabs(p->view.direction[i]);
+				if (p->view.perspective)
+					d += std::fabs(p->view.right_plane[i]) * (0.5f * (float) p->view.width + 1.0f) + std::fabs(p->view.up_plane[i]) * (0.5f * (float) p->view.height + 1.0f);
+				advance = std::fmax(advance, d * half[i]);
+			}
+			if (!((float) kDepth * p->ray_step * advance + 1.5f <= (float) kLutPad)) a.clamp_fetch = 1u;
+		}
+		if (c->force_clamp_fetch & 1u) a.clamp_fetch = 1u;
+		auto pow2 = [](uint32_t n) { return n != 0 && (n & (n - 1)) == 0; };
+		a.near_scaled = (pow2(c->dim[0]) && pow2(c->dim[1]) && pow2(c->dim[2]) && !(c->force_clamp_fetch & 2u)) ? 1u : 0u;
 	}
 	a.force_wide = c->force_wide;
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
@@ -514,7 +531,8 @@ int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	c->force_wide = force & 3u;                  // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
-	c->force_clamp_fetch = (force >> 2) & 1u;    // + 4: clamp the fetch coordinates of every sample (far-away views do that)
+	c->force_clamp_fetch = (force >> 2) & 3u;    // + 4: clamp the fetch coordinates of every sample (far-away views do that);
+	                                             // + 8: NEAREST never marches in the scaled domain (volumes with power-of-two edges do)
 	return VR_OK;
 }
 

@@ -57,9 +57,14 @@ enum : int { kAddr32 = 0, kAddrLut64 = 1, kAddrWide = 2 };
 
 // Brick address tables at FIXED LDS positions, so a lookup is one shift + one ds_read with an immediate offset:
 // z entries first ({offset(z), offset(min(z+1, Z-1))} pairs: one ds_read_b64 / b128 serves both slices), then x, then y.
+// Every table has kLutPad (vr_device.h) extra entries on both sides that repeat the edge entry (clamp addressing): a speculative
+// fetch up to kLutPad cells outside the volume still reads a valid address, so the march needs neither a coordinate clamp nor a
+// min(k, ky) per sample (the host checks that kDepth ray steps plus rounding stay below kLutPad cells, else the clamping variant runs).
 template <int ADDR> struct LutCfg          { static constexpr uint32_t max_dim = 0,    z_words = 0, x_at = 0,    y_at = 0,     words = 4,     threads = 512; };
-template <> struct LutCfg<kAddr32>         { static constexpr uint32_t max_dim = 1024, z_words = 2, x_at = 2048, y_at = 3072,  words = 4096,  threads = 512; };
-template <> struct LutCfg<kAddrLut64>      { static constexpr uint32_t max_dim = 2048, z_words = 4, x_at = 8192, y_at = 10240, words = 12288, threads = 1024; };
+template <> struct LutCfg<kAddr32>         { static constexpr uint32_t max_dim = 1024, z_words = 2, x_at = (1024 + 2 * kLutPad) * 2, y_at = x_at + 1024 + 2 * kLutPad,
+                                                                       words = y_at + 1024 + 2 * kLutPad, threads = 512; };
+template <> struct LutCfg<kAddrLut64>      { static constexpr uint32_t max_dim = 2048, z_words = 4, x_at = (2048 + 2 * kLutPad) * 4, y_at = x_at + 2048 + 2 * kLutPad,
+                                                                       words = y_at + 2048 + 2 * kLutPad, threads = 1024; };
 
 template <int BPV> struct VoxelT;
 template <> struct VoxelT<1> { typedef uint8_t type; };
@@ -67,25 +72,48 @@ template <> struct VoxelT<2> { typedef uint16_t type; };
 
 // ---- volume fetch --------------------------------------------------------------------------------------------
 
+// "Managed" gathers of the software-pipelined march: issued through inline asm, so the compiler's s_waitcnt insertion does not
+// know them and the ray loop waits for exactly the loads it is about to read (s_waitcnt vmcnt(N), N = the loads issued since).
+// Left to the compiler, the waits at the loop's control-flow joins are merged conservatively (vmcnt(1) / vmcnt(0) where vmcnt(4)
+// would do) and the prefetch distance collapses to one sample — the march then runs at memory latency, not at issue rate.
+// Only the hot instantiations use them (1-byte voxels, 32-bit table addressing, the quad or run bricks); the loop drains them
+// with s_waitcnt vmcnt(0) before it lets go of the destination registers.
+template <int BPV, int ADDR, int LAYOUT> struct Managed {
+	static constexpr bool value = BPV == 1 && ADDR == kAddr32 && (LAYOUT == kLayoutBricked || LAYOUT == kLayoutRun);
+};
+__device__ __forceinline__ void managed_load32(uint32_t &dst, uint32_t byte_offset, const void *base) {
+	asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
+}
+__device__ __forceinline__ void managed_load64(uint64_t &dst, uint64_t address) {      // split into halves only AFTER the wait
+	asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(address));
+}
+
 // Single voxel (NEAREST).  LINEAR: the reference's array.  BRICKED: component 0 of the quad element (x,y,z) IS v(x,y,z), so
 // NEAREST reads the same Z-ordered bricks as TRILINEAR with one aligned element load and keeps their view-independent
 // cache-line footprint; the value — hence the image — is identical.
-template <int BPV, int ADDR, int LAYOUT>
+template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
-                                                uint32_t ix, uint32_t iy, uint32_t iz) {
+                                                int ix, int iy, int iz) {
 	typedef typename VoxelT<BPV>::type V;
 	if (LAYOUT == kLayoutBricked) {
-		typedef LutCfg<ADDR> L;
-		const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
+		typedef LutCfg<ADDR> L;                      // table lookups take indices -kLutPad .. dim - 1 + kLutPad
+		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
 		const uint8_t *q;
 		if (ADDR == kAddr32) {
-			q = (const uint8_t *) vol + (exy + lut[L::z_words * iz]);
+			if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
+				uint32_t word;
+				managed_load32(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
+				return word;
+			}
+			q = (const uint8_t *) vol + (exy + lut[(int) L::z_words * (iz + kLutPad)]);
 		} else {
-			const uint2 z = *(const uint2 *) (lut + L::z_words * iz);
+			const uint2 z = *(const uint2 *) (lut + (int) L::z_words * (iz + kLutPad));
 			q = (const uint8_t *) vol + ((((uint64_t) z.y) << 32 | z.x) + exy);
 		}
-		if (BPV == 1) return *(const uint32_t *) q & 0xffu;
-		return *(const uint32_t *) q & 0xffffu;
+		// the RAW element word: the voxel is its low byte / half (voxel_of).  Masking here would hand the compiler an operation on the
+		// loaded value that it hoists to the loop latch of the software-pipelined march — behind an s_waitcnt vmcnt(0) that drains
+		// every prefetch once per iteration (measured: the NEAREST full march was latency bound because of it).
+		return *(const uint32_t *) q;
 	}
 	if (ADDR == kAddrWide) {
 		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
@@ -96,22 +124,40 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 	}
 }
 
+// the voxel inside what fetch_voxel returned (bricked layouts return the whole quad element)
+template <int BPV, int LAYOUT> __device__ __forceinline__ uint32_t voxel_of(uint32_t fetched) {
+	return LAYOUT == kLayoutBricked ? (BPV == 1 ? fetched & 0xffu : fetched & 0xffffu) : fetched;
+}
+
 // ModelBase.h:17-23 Model::sample_data
-template <int BPV, int ADDR, int LAYOUT>
+template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 pos) {
 	uint32_t iz = map_float_int((pos.z + 1) * 0.5f, a.dim_z);
 	uint32_t iy = map_float_int((pos.y + 1) * 0.5f, a.dim_y);
 	uint32_t ix = map_float_int((pos.x + 1) * 0.5f, a.dim_x);
-	return fetch_voxel<BPV, ADDR, LAYOUT>(vol, a, lut, ix, iy, iz);
+	return fetch_voxel<BPV, ADDR, LAYOUT, MANAGED>(vol, a, lut, (int) ix, (int) iy, (int) iz);
 }
 
-// The same voxel for a position INSIDE the cube (pos + 1 >= -1e-6): no lower clamp (a fraction above -1 truncates to 0),
-// and ((pos + 1) * 0.5f) * n == (pos + 1) * (0.5f * n) bit for bit, because both scalings by 0.5 are exact.
-template <int BPV, int ADDR, int LAYOUT>
+// The same voxel for a position INSIDE the cube, or at most kLutPad cells outside it when the layout has (padded) tables:
+// truncation alone gives the cell — a fraction above -1 truncates to 0 like the lower clamp, the upper clamp is the repeated
+// edge entry of the table — and ((pos + 1) * 0.5f) * n == (pos + 1) * (0.5f * n) bit for bit (both scalings by 0.5 are exact).
+template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ uint32_t sample_nearest_incube(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 pos) {
-	const int iz = (int) ((pos.z + 1) * a.half_z), iy = (int) ((pos.y + 1) * a.half_y), ix = (int) ((pos.x + 1) * a.half_x);
-	const int mz = (int) a.dim_z - 1, my = (int) a.dim_y - 1, mx = (int) a.dim_x - 1;
-	return fetch_voxel<BPV, ADDR, LAYOUT>(vol, a, lut, (uint32_t) (ix < mx ? ix : mx), (uint32_t) (iy < my ? iy : my), (uint32_t) (iz < mz ? iz : mz));
+	int iz = (int) ((pos.z + 1) * a.half_z), iy = (int) ((pos.y + 1) * a.half_y), ix = (int) ((pos.x + 1) * a.half_x);
+	if (!(LAYOUT == kLayoutBricked && ADDR != kAddrWide)) {             // no tables: clamp the index at the upper face
+		const int mz = (int) a.dim_z - 1, my = (int) a.dim_y - 1, mx = (int) a.dim_x - 1;
+		ix = ix < mx ? ix : mx; iy = iy < my ? iy : my; iz = iz < mz ? iz : mz;
+	}
+	return fetch_voxel<BPV, ADDR, LAYOUT, MANAGED>(vol, a, lut, ix, iy, iz);
+}
+
+// NEAREST in the SCALED domain, for volumes whose edges are powers of two: ps = origin * half + (direction * half) * k, and the
+// cell is (int)(ps + half).  Scaling by a power of two commutes with every fp32 rounding of the reference's sequence
+// t = dir * k; p = origin + t; q = p + 1; cell = (int)(q * half)   (q * half is exact), so the cell is the same bit for bit while
+// one multiplication per axis disappears from the per-sample address chain.
+template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
+__device__ __forceinline__ uint32_t sample_nearest_scaled(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 ps) {
+	return fetch_voxel<BPV, ADDR, LAYOUT, MANAGED>(vol, a, lut, (int) (ps.x + a.half_x), (int) (ps.y + a.half_y), (int) (ps.z + a.half_z));
 }
 
 __device__ __forceinline__ float lerp(float a, float b, float t) { return VR_FMA(t, b - a, a); }
@@ -129,38 +175,43 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	// bricked: slice z quad, slice z+1 quad (u8: one dword each, u16: two dwords each);
 	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
 	uint32_t w0, w1, w2, w3;
-	float xb, yb, zb;                                // texel-space coordinates of the sample (clamped in tri_resolve)
+	uint64_t q;                                      // run bricks, managed load: both slices as ONE 64-bit destination (w0 = low, w1 = high)
 };
 
 // `clamp` (wave-uniform) = false is allowed for positions INSIDE the volume's cube, i.e. coordinates in (-1, N): there
 // truncation toward zero already yields the clamped cell (x in (-1, 0) -> 0 like clamp-to-0; x in (N-1, N) -> N-1 like
 // clamp-to-N-1), so the three v_med3 are only needed for the interpolation weights, and those are computed in
 // tri_resolve, which most samples of a sparse volume never reach (transparent shortcut of the ray loop).
-template <int BPV, int ADDR, int LAYOUT>
+template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
                                                            float xb, float yb, float zb, bool clamp) {
 	TriFetch<BPV, LAYOUT> f;
-	f.xb = xb; f.yb = yb; f.zb = zb;
+	f.q = 0;
 	if (clamp) {
 		xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
 		yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
 		zb = __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
 	}
-	const uint32_t ix = (uint32_t) (int) xb, iy = (uint32_t) (int) yb, iz = (uint32_t) (int) zb;
+	const int ix = (int) xb, iy = (int) yb, iz = (int) zb;          // table layouts: -kLutPad .. dim - 1 + kLutPad are valid
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
 	if (LAYOUT == kLayoutRun) {
 		// run bricks: x / y tables hold the cell column's offset, the z table the ABSOLUTE 64-bit address of (brick slab, z & 7);
 		// slices z and z+1 are 8 adjacent bytes (the ninth element of a run duplicates the next brick's first)
 		typedef LutCfg<kAddr32> L;
-		const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
-		const uint2 zz = *(const uint2 *) (lut + 2 * iz);
-		const uint2 both = *(const uint2 *) ((((uint64_t) zz.y) << 32 | zz.x) + exy);        // global_load_dwordx2, 4-byte aligned
-		f.w0 = both.x; f.w1 = both.y;
+		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
+		const uint2 zz = *(const uint2 *) (lut + 2 * (iz + kLutPad));
+		const uint64_t address = (((uint64_t) zz.y) << 32 | zz.x) + exy;
+		if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
+			managed_load64(f.q, address);
+		} else {
+			const uint2 both = *(const uint2 *) address;                                     // global_load_dwordx2, 4-byte aligned
+			f.w0 = both.x; f.w1 = both.y;
+		}
 	} else if (LAYOUT == kLayoutBricked) {
 		constexpr uint32_t kElem = 4 * BPV;
 		const uint8_t *q0, *q1;
 		if (ADDR == kAddrWide) {
-			const uint32_t iz1 = iz + 1 < a.dim_z ? iz + 1 : iz;
+			const uint32_t iz1 = (uint32_t) iz + 1 < a.dim_z ? iz + 1 : iz;
 			const uint64_t bxy = (uint64_t) (iy >> 3) * a.nbx + (ix >> 3), slab = (uint64_t) a.nbx * a.nby;
 			const uint32_t lxy = brick_spread(BPV, a.brick_plane, 0, ix & 7u) | brick_spread(BPV, a.brick_plane, 1, iy & 7u);
 			q0 = (const uint8_t *) vol + (((iz >> 3) * slab + bxy) * kBrickPitch + (lxy | brick_spread(BPV, a.brick_plane, 2, iz & 7u))) * kElem;
@@ -168,18 +219,21 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		} else {
 			// per-axis byte-offset tables in LDS (LutCfg): brick base + Morton-dilated in-brick offset, split by axis
 			typedef LutCfg<ADDR> L;
-			const uint32_t exy = lut[L::x_at + ix] + lut[L::y_at + iy];
+			const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
 			if (ADDR == kAddr32) {
-				const uint2 zz = *(const uint2 *) (lut + L::z_words * iz);
+				const uint2 zz = *(const uint2 *) (lut + (int) L::z_words * (iz + kLutPad));
 				q0 = (const uint8_t *) vol + (exy + zz.x);
 				q1 = (const uint8_t *) vol + (exy + zz.y);
 			} else {
-				const uint4 zz = *(const uint4 *) (lut + L::z_words * iz);
+				const uint4 zz = *(const uint4 *) (lut + (int) L::z_words * (iz + kLutPad));
 				q0 = (const uint8_t *) vol + ((((uint64_t) zz.y) << 32 | zz.x) + exy);
 				q1 = (const uint8_t *) vol + ((((uint64_t) zz.w) << 32 | zz.z) + exy);
 			}
 		}
-		if (BPV == 1) {                                  // 2 x global_load_dword, 4-byte aligned
+		if (BPV == 1 && MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
+			managed_load32(f.w0, (uint32_t) (q0 - (const uint8_t *) vol), vol);
+			managed_load32(f.w1, (uint32_t) (q1 - (const uint8_t *) vol), vol);
+		} else if (BPV == 1) {                           // 2 x global_load_dword, 4-byte aligned
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
 		} else {                                         // 2 x global_load_dwordx2, 8-byte aligned
@@ -216,11 +270,13 @@ template <bool Q8> __device__ __forceinline__ float filter_weight(float w) {
 	return Q8 ? __builtin_rintf(w * 256.0f) * (1.0f / 256.0f) : w;
 }
 
+// (xb, yb, zb): the texel-space coordinates the words were fetched at; the fetch slots of the march do not carry them — the few
+// samples that get this far recompute them from the sample's k (three fused multiply-adds, the same values bit for bit)
 template <int BPV, int LAYOUT, bool Q8>
-__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a) {
-	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.xb, 0.0f, a.max_x)));
-	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.yb, 0.0f, a.max_y)));
-	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(f.zb, 0.0f, a.max_z)));
+__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a, float xb, float yb, float zb) {
+	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x)));
+	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y)));
+	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z)));
 	float v000, v100, v010, v110, v001, v101, v011, v111;
 	if (LAYOUT != kLayoutLinear) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
@@ -352,6 +408,25 @@ __device__ __forceinline__ f3 march_point(f3 origin, f3 dir, float k) {
 	return mk3(VR_FMA(dir.x, k, origin.x), VR_FMA(dir.y, k, origin.y), VR_FMA(dir.z, k, origin.z));
 }
 
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&body) {
+	if constexpr (I < N) { body(std::integral_constant<int, I>()); static_for<I + 1, N>(body); }
+}
+// keeps a value in its register across this point (an inline-asm operand must not be a lambda capture, hence the functions)
+__device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(uint32_t &x, uint32_t &y) { asm volatile("" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void pin(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) { asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w)); }
+__device__ __forceinline__ void pin(uint64_t &x) { asm volatile("" : "+v"(x)); }
+template <int I> __device__ __forceinline__ void managed_wait() {       // s_waitcnt vmcnt(I): all but the I youngest gathers have landed
+	static_assert(I >= 0 && I <= 15, "vmcnt");
+	if constexpr (I == 0) asm volatile("s_waitcnt vmcnt(0)"); else if constexpr (I == 1) asm volatile("s_waitcnt vmcnt(1)");
+	else if constexpr (I == 2) asm volatile("s_waitcnt vmcnt(2)"); else if constexpr (I == 3) asm volatile("s_waitcnt vmcnt(3)");
+	else if constexpr (I == 4) asm volatile("s_waitcnt vmcnt(4)"); else if constexpr (I == 5) asm volatile("s_waitcnt vmcnt(5)");
+	else if constexpr (I == 6) asm volatile("s_waitcnt vmcnt(6)"); else if constexpr (I == 7) asm volatile("s_waitcnt vmcnt(7)");
+	else if constexpr (I == 8) asm volatile("s_waitcnt vmcnt(8)"); else if constexpr (I == 9) asm volatile("s_waitcnt vmcnt(9)");
+	else if constexpr (I == 10) asm volatile("s_waitcnt vmcnt(10)"); else if constexpr (I == 11) asm volatile("s_waitcnt vmcnt(11)");
+	else if constexpr (I == 12) asm volatile("s_waitcnt vmcnt(12)"); else asm volatile("s_waitcnt vmcnt(13)");
+}
+
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
@@ -372,33 +447,37 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	// -- stage TF (+ deltas), the ESL bit-volume and the brick address tables in LDS
 	{
 		const uint32_t t = threadIdx.x;
+		// entry j of a table belongs to cell clamp(j - kLutPad, 0, dim - 1): the pad entries repeat the edge cells
+		auto cell_of = [](uint32_t j, uint32_t n) { const int c = (int) j - kLutPad; return (uint32_t) (c < 0 ? 0 : (c > (int) n - 1 ? (int) n - 1 : c)); };
 		if (kUseLut && LAYOUT == kLayoutRun) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
 			const uint64_t slab = (uint64_t) a.nbx * a.nby * kRunBrickBytes;                  // bricks: x fastest, then y, then z
-			for (uint32_t i = t; i < nz; i += kThreads) {
+			for (uint32_t j = t; j < nz + 2 * kLutPad; j += kThreads) {
+				const uint32_t i = cell_of(j, nz);
 				const uint64_t z0 = (uint64_t) (uintptr_t) vol + (i >> 3) * slab + (i & 7u) * 4u;
-				lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) (z0 >> 32);
+				lut[2 * j] = (uint32_t) z0; lut[2 * j + 1] = (uint32_t) (z0 >> 32);
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = (i >> 3) * kRunBrickBytes + run_cell_spread(0, i & 7u);
-			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u);
+			for (uint32_t j = t; j < nx + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, nx); lut[L::x_at + j] = (i >> 3) * kRunBrickBytes + run_cell_spread(0, i & 7u); }
+			for (uint32_t j = t; j < ny + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, ny); lut[L::y_at + j] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u); }
 		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
 			const uint32_t elem = 4u * BPV;                                  // bytes per quad element
 			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
 			const uint64_t slab = (uint64_t) a.nby * row;
-			for (uint32_t i = t; i < nz; i += kThreads) {
+			for (uint32_t jj = t; jj < nz + 2 * kLutPad; jj += kThreads) {
+				const uint32_t i = cell_of(jj, nz);
 				const uint32_t j = i + 1 < nz ? i + 1 : i;
 				const uint64_t z0 = ((i >> 3) * slab + brick_spread(BPV, a.brick_plane, 2, i & 7u)) * elem;
 				const uint64_t z1 = ((j >> 3) * slab + brick_spread(BPV, a.brick_plane, 2, j & 7u)) * elem;
 				if (ADDR == kAddr32) {
-					lut[2 * i] = (uint32_t) z0; lut[2 * i + 1] = (uint32_t) z1;
+					lut[2 * jj] = (uint32_t) z0; lut[2 * jj + 1] = (uint32_t) z1;
 				} else {
-					lut[4 * i] = (uint32_t) z0; lut[4 * i + 1] = (uint32_t) (z0 >> 32);
-					lut[4 * i + 2] = (uint32_t) z1; lut[4 * i + 3] = (uint32_t) (z1 >> 32);
+					lut[4 * jj] = (uint32_t) z0; lut[4 * jj + 1] = (uint32_t) (z0 >> 32);
+					lut[4 * jj + 2] = (uint32_t) z1; lut[4 * jj + 3] = (uint32_t) (z1 >> 32);
 				}
 			}
-			for (uint32_t i = t; i < nx; i += kThreads) lut[L::x_at + i] = ((i >> 3) * kBrickPitch + brick_spread(BPV, a.brick_plane, 0, i & 7u)) * elem;
-			for (uint32_t i = t; i < ny; i += kThreads) lut[L::y_at + i] = ((i >> 3) * row + brick_spread(BPV, a.brick_plane, 1, i & 7u)) * elem;
+			for (uint32_t j = t; j < nx + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, nx); lut[L::x_at + j] = ((i >> 3) * kBrickPitch + brick_spread(BPV, a.brick_plane, 0, i & 7u)) * elem; }
+			for (uint32_t j = t; j < ny + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, ny); lut[L::y_at + j] = ((i >> 3) * row + brick_spread(BPV, a.brick_plane, 1, i & 7u)) * elem; }
 		}
 		if (t <= VR_TF_SIZE) {
 			const f4 *tf4 = (const f4 *) tf_g;
@@ -550,31 +629,56 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
 		uint64_t live = __builtin_amdgcn_ballot_w64(alive);            // liveness as one scalar wave mask (see TRILINEAR)
 		if (!alive) { kx = 0.0f; ky = 0.0f; origin = mk3(0.0f, 0.0f, 0.0f); dir = origin; pt = origin; }
-		auto march = [&](auto clamp_tag) {
+		constexpr bool kTables = LAYOUT == kLayoutBricked && ADDR != kAddrWide;       // padded address tables (kLutPad)
+		auto march = [&](auto clamp_tag, auto scaled_tag) {
 		constexpr bool kClamp = decltype(clamp_tag)::value;
-		auto fetch = [&](f3 p) {
-			return kClamp ? sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, p) : sample_nearest_incube<BPV, ADDR, LAYOUT>(vol, a, lut, p);
+		// kFree: fetch positions are NOT pulled back to the ray's segment — a finished lane's k simply stops (its step becomes 0, a
+		// wave-uniform branch when a lane finishes), so a speculative position lies at most two steps past the exit point, inside
+		// the table padding.  Otherwise (no tables, or the clamping variant) every fetch position is taken at min(k, ky) / clamped.
+		constexpr bool kFree = !kClamp && kTables;
+		constexpr bool kScaled = kFree && decltype(scaled_tag)::value;               // sample_nearest_scaled
+		const f3 so = kScaled ? mk3(origin.x * a.half_x, origin.y * a.half_y, origin.z * a.half_z) : origin;
+		const f3 sd = kScaled ? mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z) : dir;
+		float step_v = kFree ? select_lanes(live, step) : step;
+		auto fetch_at = [&](float k) {
+			if (!kClamp && !kFree) k = __builtin_fminf(k, ky);
+			const f3 p = mk3(so.x + sd.x * k, so.y + sd.y * k, so.z + sd.z * k);      // CPURenderer.cpp:17,24,38: two roundings per axis
+			if (kClamp) return sample_nearest<BPV, ADDR, LAYOUT, true>(vol, a, lut, p);
+			if (kScaled) return sample_nearest_scaled<BPV, ADDR, LAYOUT, true>(vol, a, lut, p);
+			return sample_nearest_incube<BPV, ADDR, LAYOUT, true>(vol, a, lut, p);
 		};
-		// two samples ahead, like the TRILINEAR loop: (k1, p1) are the next sample, the fetch issued here is the one after it
-		float k1 = kx + step;
-		f3 p1 = march_point<SAMPLING>(origin, dir, kClamp ? k1 : __builtin_fminf(k1, ky));
-		auto step_sample = [&](const uint32_t &cur_s, uint32_t &nxt_s) {
-			const float kn = k1, k2 = k1 + step;
-			const f3 pn = p1, p2 = march_point<SAMPLING>(origin, dir, kClamp ? k2 : __builtin_fminf(k2, ky));
-			nxt_s = fetch(p2);
+		constexpr bool kManaged = Managed<BPV, ADDR, LAYOUT>::value;
+		// kDepth samples ahead: slot j carries the fetched word and the k of its sample
+		uint32_t word[kSlots]; float ks[kSlots];
+		ks[0] = kx; word[kSlots - 1] = 0;
+		static_for<0, kDepth>([&](auto j) {
+			if constexpr (j.value > 0) ks[j.value] = ks[j.value - 1] + step_v;
+			word[j.value] = fetch_at(ks[j.value]);
+		});
+		auto step_sample = [&](auto jc) {
+			constexpr int c = decltype(jc)::value, n = (c + kDepth) % kSlots, nx = (c + 1) % kSlots;
+			ks[n] = ks[(n + kSlots - 1) % kSlots] + step_v;
+			word[n] = fetch_at(ks[n]);
 			__builtin_amdgcn_sched_barrier(0);
-			const uint32_t s = cur_s;
+			kx = ks[c];
+			const float kn = ks[nx];
+			// Nothing that reads the fetched word may move above this point: the compiler otherwise hoists such work to the loop latch,
+			// behind an s_waitcnt vmcnt(0) that drains the prefetches in flight once per iteration.
+			if (kManaged) { pin(word[c]); managed_wait<kDepth>(); pin(word[c]); }
+			else pin(word[c]);
+			const uint32_t s = voxel_of<BPV, LAYOUT>(word[c]);
 			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
 			if ((__builtin_amdgcn_sicmp((int) idx, tf_zero_idx, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 				f4 cur = lds.tf[idx];
 				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
 				if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
 					const float raw = BPV == 1 ? 255.0f : 65535.0f;
+					pt = march_point<SAMPLING>(origin, dir, kx);                                  // the sample's own position
 					f3 d = mk3(light.x - pt.x, light.y - pt.y, light.z - pt.z);
 					float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 					f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 					f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
-					const uint32_t s_l = sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps);
+					const uint32_t s_l = voxel_of<BPV, LAYOUT>(sample_nearest<BPV, ADDR, LAYOUT>(vol, a, lut, ps));
 					const float sl = BPV == 1 ? lds.unit[s_l] : (float) s_l / raw;                  // RaycasterBase.h:93-96
 					const float sc = BPV == 1 ? lds.unit[s] : (float) s / raw;
 					const float diffuse = select_lanes(shaded, (sl - sc) * kd);                   // x + 0 == x: unshaded lanes unchanged
@@ -584,19 +688,23 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
 				acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
 				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                      // CPURenderer.cpp:35-36
+				if (kFree) step_v = select_lanes(live, step);                                     // terminated rays stop marching
 			}
-			live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
-			kx = kn; pt = pn;
-			k1 = k2; p1 = p2;
+			const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
+			if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);      // a lane has just left its segment
+			live &= still;
 		};
-		uint32_t sa = fetch(pt), sb = fetch(p1), sc = 0;
-		while (live != 0ull) {
-			step_sample(sa, sc);
-			step_sample(sb, sa);
-			step_sample(sc, sb);
+		while (live != 0ull)
+			static_for<0, kSlots>(step_sample);
+		if (kManaged) {                                              // nothing in flight into registers we release
+			static_for<0, kSlots>([&](auto j) { pin(word[j.value]); });
+			managed_wait<0>();
+			static_for<0, kSlots>([&](auto j) { pin(word[j.value]); });
 		}
 		};
-		if (a.clamp_fetch) march(std::true_type()); else march(std::false_type());
+		if (a.clamp_fetch) march(std::true_type(), std::false_type());
+		else if (kTables && a.near_scaled) march(std::false_type(), std::true_type());
+		else march(std::false_type(), std::false_type());
 	} else {
 		// texel-space ray: coordinate = fma(k, A, B) (see oracle/vr_oracle.c axis_setup)
 		f3 A = mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z);
@@ -609,40 +717,46 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// had a segment march the constant position 0.  The host switches the coordinate clamp back on (clamp_fetch) for
 		// views so far from the volume that fp32 rounding of the coordinates could leave (-1, N).
 		if (!alive) { kx = 0.0f; ky = 0.0f; A = mk3(0.0f, 0.0f, 0.0f); B = A; }
+		constexpr bool kTables = LAYOUT != kLayoutLinear && ADDR != kAddrWide;        // padded address tables (kLutPad)
 		auto march = [&](auto clamp_tag) {                    // instantiated for both settings: no per-sample test of the flag
 			constexpr bool kClamp = decltype(clamp_tag)::value;
-			// Software pipeline: the loads of sample i+2 (VR_PREFETCH_DEPTH; i+1 with depth 1) are issued before sample i is
+			constexpr bool kFree = !kClamp && kTables;        // see the NEAREST loop: no min(k, ky), finished lanes stop instead
+			// Software pipeline: the loads of sample i+2 are issued before sample i is
 			// unpacked, filtered and composited, so memory round trips overlap the arithmetic inside every wave (on top of the
 			// 8 waves per SIMD).  The body is written once (`step_sample`) and instantiated once per fetch slot and iteration
 			// with the slots rotated: no register copies, one exit vote per three samples (a finished wave at worst composites
 			// two more weight-0 samples).
 			auto issue = [&](float k) {
-				if (!kClamp) k = __builtin_fminf(k, ky);
-				return tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
+				if (!kClamp && !kFree) k = __builtin_fminf(k, ky);
+				return tri_issue<BPV, ADDR, LAYOUT, true>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
 			};
+			constexpr bool kManaged = Managed<BPV, ADDR, LAYOUT>::value;
 			const uint64_t skip_never = a.skip_never ? ~0ull : 0ull;
 			// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
 			// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
 			// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
 			uint64_t live = __builtin_amdgcn_ballot_w64(alive);
-#ifndef VR_PREFETCH_DEPTH
-#define VR_PREFETCH_DEPTH 2
-#endif
-#if VR_PREFETCH_DEPTH == 2
-			float k1 = kx + step;                                  // k of the sample after the current one
-#endif
-			auto step_sample = [&](const TriFetch<BPV, LAYOUT> &cur, TriFetch<BPV, LAYOUT> &nxt) {
-#if VR_PREFETCH_DEPTH == 2
-				const float kn = k1;                               // `nxt` receives the fetch of the sample TWO steps ahead
-				const float k2 = k1 + step;
-				nxt = issue(k2);
-#else
-				const float kn = kx + step;
-				nxt = issue(kn);
-#endif
+			float step_v = kFree ? select_lanes(live, step) : step;       // per-lane step: 0 once the lane is finished
+			// kDepth samples ahead (one less for 2-byte voxels, whose slots hold four words: 64 VGPRs keep 8 waves per SIMD):
+			// slot j carries the fetched words and the k of its sample
+			constexpr int kDepth = BPV == 1 ? vr::kDepth : (vr::kDepth > 1 ? vr::kDepth - 1 : 1), kSlots = kDepth + 1;
+			TriFetch<BPV, LAYOUT> f[kSlots]; float ks[kSlots];
+			ks[0] = kx;
+			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0;
+			static_for<0, kDepth>([&](auto j) {
+				if constexpr (j.value > 0) ks[j.value] = ks[j.value - 1] + step_v;
+				f[j.value] = issue(ks[j.value]);
+			});
+			auto step_sample = [&](auto jc) {
+				constexpr int c = decltype(jc)::value, n = (c + kDepth) % kSlots, nx = (c + 1) % kSlots;
+				ks[n] = ks[(n + kSlots - 1) % kSlots] + step_v;
+				f[n] = issue(ks[n]);
 #ifndef VR_NO_SCHED_BARRIER
 				__builtin_amdgcn_sched_barrier(0);
 #endif
+				TriFetch<BPV, LAYOUT> &cur = f[c];
+				kx = ks[c];
+				const float kn = ks[nx];
 				// Exact shortcuts, decided per wave.  Entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
 				// default TF is zero below 10 % density), so a sample whose TF coordinate tb is <= tf_zero_below has colour
 				// (0,0,0,0), is never shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.
@@ -651,11 +765,21 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				//      operands, fp32 rounding included — and skip_below was chosen on the host so that tb <= tf_zero_below
 				//      follows: the wave skips unpacking, the 7 lerps and everything after them;
 				//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
+				// pinned below the issue (see the NEAREST loop), on the slot's own registers: waits only for the slot's loads
+				if (kManaged && LAYOUT == kLayoutRun) {                // one 8-byte gather per slot: kDepth younger ones may be in flight
+					pin(cur.q); managed_wait<kDepth>(); pin(cur.q);
+					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32);
+				} else if (kManaged) {                                 // two 4-byte gathers per slot: 2 * kDepth younger ones
+					pin(cur.w0, cur.w1); managed_wait<2 * kDepth>(); pin(cur.w0, cur.w1);
+				} else if (LAYOUT != kLayoutLinear && BPV == 1) pin(cur.w0, cur.w1);
+				else pin(cur.w0, cur.w1, cur.w2, cur.w3);
+				const TriFetch<BPV, LAYOUT> &now = cur;
 				uint32_t corners;
-				if (LAYOUT != kLayoutLinear) corners = BPV == 1 ? (cur.w0 | cur.w1) : (cur.w0 | cur.w1 | cur.w2 | cur.w3);
-				else                          corners = cur.w0 | cur.w1 | cur.w2 | cur.w3;
+				if (LAYOUT != kLayoutLinear) corners = BPV == 1 ? (now.w0 | now.w1) : (now.w0 | now.w1 | now.w2 | now.w3);
+				else                          corners = now.w0 | now.w1 | now.w2 | now.w3;
 				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
-				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(cur, a);                                    // GPURenderer4.cu:76
+				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);       // where the words were fetched
+				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(now, a, xb, yb, zb);                          // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
 				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
 				if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
@@ -669,13 +793,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					}
 					const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
 					if (shaded != 0ull) {                                                              // GPURenderer4.cu:41-51 shade_texture
-						const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
 						const f3 p3 = march_point<SAMPLING>(origin, dir, kx);
 						const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
 						const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-						TriFetch<BPV, LAYOUT> lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, VR_FMA(d.x * inv, a.lh_x, xb),
-						                                                        VR_FMA(d.y * inv, a.lh_y, yb), VR_FMA(d.z * inv, a.lh_z, zb), true);
-						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a);
+						const float lx = VR_FMA(d.x * inv, a.lh_x, xb), ly = VR_FMA(d.y * inv, a.lh_y, yb), lz = VR_FMA(d.z * inv, a.lh_z, zb);
+						TriFetch<BPV, LAYOUT> lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, lx, ly, lz, true);
+						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a, lx, ly, lz);
 						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 						c.x += diffuse; c.y += diffuse; c.z += diffuse;
 					}
@@ -683,30 +806,21 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y);
 					acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
 					live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                        // ERT (CPURenderer.cpp:35-36)
+					if (kFree) step_v = select_lanes(live, step);                                       // terminated rays stop marching
 				}
 				}
-				live &= __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                                       // the loop condition
-				kx = kn;
-#if VR_PREFETCH_DEPTH == 2
-				k1 = k2;
-#endif
+				const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                        // the loop condition
+				if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);        // a lane has just left its segment
+				live &= still;
 			};
-#if VR_PREFETCH_DEPTH == 2
-			TriFetch<BPV, LAYOUT> fa = issue(kx), fb = issue(k1), fc;
-			while (live != 0ull) {
-				step_sample(fa, fc);
-				step_sample(fb, fa);
-				step_sample(fc, fb);
+			while (live != 0ull)
+				static_for<0, kSlots>(step_sample);
+			if (kManaged) {                                            // nothing in flight into registers we release
+				auto pin_slot = [&](auto j) { if (LAYOUT == kLayoutRun) pin(f[j.value].q); else pin(f[j.value].w0, f[j.value].w1); };
+				static_for<0, kSlots>(pin_slot);
+				managed_wait<0>();
+				static_for<0, kSlots>(pin_slot);
 			}
-#else
-			TriFetch<BPV, LAYOUT> fa = issue(kx), fb;
-			while (live != 0ull) {
-				step_sample(fa, fb);
-				step_sample(fb, fa);
-				step_sample(fa, fb);                 // four samples per exit vote (-2.5 % against two)
-				step_sample(fb, fa);
-			}
-#endif
 		};
 		if (a.clamp_fetch) march(std::true_type()); else march(std::false_type());
 	}
