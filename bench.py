@@ -156,7 +156,7 @@ def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
     else:
         rays, secs = port_leg(band_rows, 1)
         kind = "port"
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     all_rows = min(height // len(views), 4 * band_rows)
     a_rays, a_secs = port_leg(all_rows, cores)
     return {"value": round(rays / secs / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": kind,
@@ -166,6 +166,22 @@ def cpu_baseline(vr, renderer, scene, views, n, width, height, band_rows):
             "all_cores": {"value": round(a_rays / a_secs / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                           "sample": f"OpenMP over rows (oracle/vr_oracle.c), {len(views)} bands x {all_rows} rows = {a_rays} rays, "
                                     f"{a_secs:.1f} s", "ms_per_frame_extrapolated": round(a_secs / a_rays * width * height * 1e3, 1)}}
+
+
+def usable_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a share of its
+    cores to every tenant; running the OpenMP leg on every core the mask shows would only oversubscribe that share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
 
 
 def recorded(path, key):
@@ -366,9 +382,12 @@ def run_rank(a):
                 "traffic": traffic.get("bytes_per_launch"), "traffic_commit": traffic.get("commit"),
                 "traffic_kernel_ms": traffic.get("kernel_ms"),
                 "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "kernel_instantiations": "raymarch_kernel<sampling,1,0,1> (quad bricks: views along a volume axis) and <sampling,1,0,2> (run bricks: "
+                                         "every other view); kernel_ms = hipEvent mean over ALL timed launches of both",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
-                "note": "full march is gather/VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling')"}
+                "note": "full march is gather / VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "
+                        "exact per-wave shortcuts (transparent samples, rays whose accumulated alpha is exactly 1) skip arithmetic only"}
             out["minmax_feeder"] = {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
                                     "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),
                                     "frac_of_hbm_peak": round(n ** 3 / (minmax_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

@@ -6,9 +6,12 @@
  *
  * Parity status: PINNED.  NEAREST mode is checked bit-for-bit against the reference's own CPURenderer
  * compiled here from /root/reference (oracle/_ref, see oracle/Makefile) and against the committed
- * fixtures in tests/golden/ generated from it (oracle/gen_golden.py).  TRILINEAR mode restates
- * GPURenderer4.cu's texture semantics, which cannot be compiled here (no nvcc): it is pinned only by
- * the CUDA texture-filtering definition — "parity unpinned" for that mode against the reference.
+ * fixtures in tests/golden/ generated from it (oracle/gen_golden.py, oracle/gen_golden_fullsize.py).
+ * The TRILINEAR modes restate GPURenderer4.cu's texture semantics, which cannot be compiled here (no nvcc):
+ * against the reference's renderer 4 itself they stay "parity unpinned"; what IS pinned, with stated
+ * tolerances asserted in tests/test_trilinear_pinning.py: the fp32 restatement against the
+ * published linear-filtering model evaluated in double precision (VRO_SAMPLE_TRILINEAR_F64 below), the 8-bit
+ * weight variant against the fp32 one, and the model difference against the reference's CPURenderer frames.
  */
 #ifndef VR_ORACLE_H
 #define VR_ORACLE_H

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for bench.py on the GPU box: kernel-trace stats + separate PMC passes (FETCH_SIZE, WRITE_SIZE).
 # Outputs under gpurun_out/profile_<tag>/ ; copy the summaries you want judged into profiles/.
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
