@@ -141,8 +141,8 @@ int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
 /* Which of the up to three brick copies the TRILINEAR fetch reads — they differ in the plane, (x,y) / (x,z) / (y,z), that the
  * 16-byte chunks of the brick order cover (volume-rendering_amd/csrc/vr_device.h): -1 = per view, the plane perpendicular to
  * the view's dominant axis (default); 0, 1, 2 = always that plane (where the copy exists: 1-byte voxels, edges up to 1024,
- * else (x,y)); 3 = the "run bricks", a fourth copy in which the slices z and z+1 of a sample are 8 adjacent bytes (one gather
- * per sample), which per-view selection uses for every view that is not along a volume axis.  Speed only; testing and tuning
+ * else (x,y)); 3 / 4 = the "run bricks", copies in which the two slices of a sample along z / along y are 8 adjacent bytes (one
+ * gather per sample), which per-view selection uses for every view whose lane quads cannot be chunk-aligned.  Speed only; testing and tuning
  * aid.  No reference counterpart. */
 int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
@@ -223,7 +223,7 @@ typedef struct vr_volume_info {
 	uint32_t brick_copies_wanted;   /* copies the layout policy asks for at this size (3: u8 with edges <= 1024, else 1; 0: linear) */
 	uint32_t brick_planes;          /* bit i set = the copy with chunk plane i (0 (x,y), 1 (x,z), 2 (y,z)) is resident */
 	uint32_t linear_resident;       /* 1 while the linear array is in HBM */
-	uint32_t run_copy;              /* 1 when the run bricks (one 8-byte gather per sample, read by views off the volume axes) are resident */
+	uint32_t run_copy;              /* run bricks resident (one 8-byte gather per sample): bit 0 runs along z, bit 1 runs along y */
 	uint64_t linear_bytes, bricked_bytes;
 } vr_volume_info;
 int vr_hip_volume_info(vr_ctx *ctx, vr_volume_info *out);

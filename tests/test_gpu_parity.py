@@ -144,7 +144,7 @@ def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
             gpu.set_layout(vr.LAYOUT_LINEAR)
             assert np.array_equal(gpu.render_volume(p), ref), (name, label, "linear")
             gpu.set_layout(vr.LAYOUT_BRICKED)
-            for plane in (-1, 0, 1, 2, 3):       # brick copy per view, then each chunk plane and the run bricks forced (vr_hip_set_brick_plane)
+            for plane in (-1, 0, 1, 2, 3, 4):    # brick copy per view, then each chunk plane and both run-brick copies forced (vr_hip_set_brick_plane)
                 gpu.set_brick_plane(plane)
                 assert np.array_equal(gpu.render_volume(p), ref), (name, label, plane)
             gpu.set_brick_plane(-1)
@@ -336,7 +336,7 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         info = r.volume_info()
         assert (info.dim_x, info.dim_y, info.dim_z, info.bytes_per_voxel) == (32, 32, 32, 1)
         assert info.layout == vr.LAYOUT_BRICKED and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7
-        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.run_copy == 1 and info.bricked_bytes == 3 * 4 * 32 ** 3 + 4 * 4 * 4 * 2304 + 16
+        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.run_copy == 3 and info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16)
         case = [c for c in golden.cases(True) if c["label"] == "bench256_view1_default"][0]
         before = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
         r.release_linear_copy()

@@ -41,7 +41,8 @@ struct vr_ctx {
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
 	void *vol_bricked = nullptr;            // brick copy with chunk plane (x,y) (vr_device.h), built by set_volume
 	void *vol_plane[kPlanes] = { nullptr, nullptr, nullptr };   // [0] = vol_bricked; [1], [2]: chunk planes (x,z), (y,z) — u8, edges <= 1024
-	void *vol_run = nullptr;                // run bricks (vr_device.h kLayoutRun): one 8-byte gather per sample, read by oblique views
+	void *vol_run = nullptr;                // run bricks (vr_device.h kLayoutRun, runs along z): one 8-byte gather per sample
+	void *vol_run_y = nullptr;              // run bricks with the runs along y (kLayoutRunY): for views that march mostly along z
 	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
 	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
 	uint32_t layout = VR_LAYOUT_BRICKED;
@@ -277,6 +278,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
 	const void *brick_copy = nullptr;
 	bool run_candidate = false, run_if_unaligned = false;
+	uint32_t run_layout = kLayoutRun;        // which run copy a run-brick frame reads: runs along z unless the view marches along z
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
 	a.brick_plane = kPlaneXY;
@@ -289,21 +291,23 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			const float dx = std::fabs(p->view.direction[0] * a.half_x), dy = std::fabs(p->view.direction[1] * a.half_y),
 			            dz = std::fabs(p->view.direction[2] * a.half_z);
 			const float dmax = std::fmax(dx, std::fmax(dy, dz));
+			if (dz >= dx && dz >= dy && c->vol_run_y) run_layout = kLayoutRunY;     // runs across the march, never along it
 			if (dmax > 0.98f * std::sqrt(dx * dx + dy * dy + dz * dz)) {
 				plane = dz >= dx && dz >= dy ? kPlaneXY : (dy >= dx ? kPlaneXZ : kPlaneYZ);
 				// Perspective along x or y: the pixel pitch grows from 0.4 to 1.1 cells along the march, most lane quads straddle
 				// chunks, and the run bricks — whose runs (along z) then lie across the march — are faster (measured 2.08 / 2.18 ms
 				// against 2.49 / 2.51 ms on the benchmark poses).  Along z the runs lie along the march and the quad copy wins
 				// (2.48 against 2.99 ms).  Orthogonal views along an axis are decided below, from how well their quads can be aligned.
-				if (p->view.perspective && plane != kPlaneXY) run_candidate = true;
+				if (p->view.perspective && (plane != kPlaneXY || c->vol_run_y)) run_candidate = true;
 				else if (!p->view.perspective) run_if_unaligned = true;
 			} else {
 				run_candidate = true;       // not along an axis: lane quads straddle chunks whatever the plane -> one 8-byte gather
 			}
 		}
 		if (plane < kPlanes && c->vol_plane[plane]) a.brick_plane = plane;
-		else if (plane == kPlanes && c->vol_run) a.layout = kLayoutRun;
-		if (run_candidate && c->vol_run) a.layout = kLayoutRun;
+		else if (plane == kPlanes && c->vol_run) a.layout = kLayoutRun;               // forced: 3 = runs along z, 4 = runs along y
+		else if (plane == kPlanes + 1 && c->vol_run_y) a.layout = kLayoutRunY;
+		if (run_candidate && c->vol_run) a.layout = run_layout;
 	}
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
@@ -331,9 +335,10 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		// An orthogonal view along an axis whose pixels sit exactly on cell boundaries can carry rounding noise in its direction
 		// (pose (180,90,0): components of 4e-8) that moves boundary pixels to the other neighbour part-way along the ray and
 		// differently across the frame: no phase aligns it.  Measured on that pose: 3.18 ms with the run bricks against 3.71 ms.
-		if (run_if_unaligned && c->vol_run && hit->straddle_permille > 150u) a.layout = kLayoutRun;
+		if (run_if_unaligned && c->vol_run && hit->straddle_permille > 150u) a.layout = run_layout;
 	}
 	if (a.layout == kLayoutRun) brick_copy = c->vol_run;
+	else if (a.layout == kLayoutRunY) brick_copy = c->vol_run_y;
 	else if (a.layout == kLayoutBricked) brick_copy = c->vol_plane[a.brick_plane];
 
 	EventPair &ev = c->ring[c->ring_head];
@@ -355,6 +360,7 @@ int ready(vr_ctx *c) {
 void free_bricks(vr_ctx *c) {
 	for (uint32_t i = 0; i < kPlanes; i++) if (c->vol_plane[i]) { (void) hipFree(c->vol_plane[i]); c->vol_plane[i] = nullptr; }
 	if (c->vol_run) { (void) hipFree(c->vol_run); c->vol_run = nullptr; }
+	if (c->vol_run_y) { (void) hipFree(c->vol_run_y); c->vol_run_y = nullptr; }
 	c->vol_bricked = nullptr;
 }
 
@@ -397,7 +403,11 @@ int finalize_volume(vr_ctx *c) {
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && run_bytes < free_b && free_b - run_bytes >= total_b / 2) {
 			if (hipMalloc(&c->vol_run, run_bytes) != hipSuccess) { c->vol_run = nullptr; (void) hipGetLastError(); }
-			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run, c->dim[0], c->dim[1], c->dim[2], c->stream));
+			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run, kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream));
+		}
+		if (c->vol_run && hipMemGetInfo(&free_b, &total_b) == hipSuccess && run_bytes < free_b && free_b - run_bytes >= total_b / 2) {
+			if (hipMalloc(&c->vol_run_y, run_bytes) != hipSuccess) { c->vol_run_y = nullptr; (void) hipGetLastError(); }
+			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run_y, kLayoutRunY, c->dim[0], c->dim[1], c->dim[2], c->stream));
 		}
 	}
 	VR_TRY(c, hipStreamSynchronize(c->stream));
@@ -538,7 +548,7 @@ int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 
 int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	if (plane < -1 || plane > (int32_t) kPlanes) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z) or 3 (run bricks)");
+	if (plane < -1 || plane > (int32_t) kPlanes + 1) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z) or 4 (run bricks along y)");
 	c->brick_plane_force = plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane
 	return VR_OK;
@@ -675,7 +685,8 @@ int vr_hip_volume_info(vr_ctx *c, vr_volume_info *out) {
 	const uint64_t copy_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
 	for (uint32_t i = 0; i < kPlanes; i++)
 		if (c->vol_plane[i]) { out->brick_planes |= 1u << i; out->brick_copies++; out->bricked_bytes += copy_bytes; }
-	if (c->vol_run) { out->run_copy = 1u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
+	if (c->vol_run) { out->run_copy |= 1u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
+	if (c->vol_run_y) { out->run_copy |= 2u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
 	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? ((c->bpv == 1 && std::max(c->dim[0], std::max(c->dim[1], c->dim[2])) <= 1024u && copy_bytes <= (1ull << 32)) ? 3u : 1u) : 0u;
 	return VR_OK;
 }

@@ -79,7 +79,7 @@ template <> struct VoxelT<2> { typedef uint16_t type; };
 // Only the hot instantiations use them (1-byte voxels, 32-bit table addressing, the quad or run bricks); the loop drains them
 // with s_waitcnt vmcnt(0) before it lets go of the destination registers.
 template <int BPV, int ADDR, int LAYOUT> struct Managed {
-	static constexpr bool value = BPV == 1 && ADDR == kAddr32 && (LAYOUT == kLayoutBricked || LAYOUT == kLayoutRun);
+	static constexpr bool value = BPV == 1 && ADDR == kAddr32 && (LAYOUT == kLayoutBricked || is_run_layout(LAYOUT));
 };
 __device__ __forceinline__ void managed_load32(uint32_t &dst, uint32_t byte_offset, const void *base) {
 	asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
@@ -194,12 +194,14 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 	}
 	const int ix = (int) xb, iy = (int) yb, iz = (int) zb;          // table layouts: -kLutPad .. dim - 1 + kLutPad are valid
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
-	if (LAYOUT == kLayoutRun) {
-		// run bricks: x / y tables hold the cell column's offset, the z table the ABSOLUTE 64-bit address of (brick slab, z & 7);
-		// slices z and z+1 are 8 adjacent bytes (the ninth element of a run duplicates the next brick's first)
+	if (is_run_layout(LAYOUT)) {
+		// run bricks: two tables hold the cell column's offset, the third the ABSOLUTE 64-bit address of (brick slab, run coordinate
+		// & 7); the two slices along the run axis are 8 adjacent bytes (the ninth element of a run duplicates the next brick's first).
+		// kLayoutRun: runs along z, columns (x,y); kLayoutRunY: runs along y, columns (x,z) — the table regions swap roles.
 		typedef LutCfg<kAddr32> L;
-		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
-		const uint2 zz = *(const uint2 *) (lut + 2 * (iz + kLutPad));
+		const int irun = LAYOUT == kLayoutRunY ? iy : iz, iother = LAYOUT == kLayoutRunY ? iz : iy;
+		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iother];
+		const uint2 zz = *(const uint2 *) (lut + 2 * (irun + kLutPad));
 		const uint64_t address = (((uint64_t) zz.y) << 32 | zz.x) + exy;
 		if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 			managed_load64(f.q, address);
@@ -278,7 +280,10 @@ __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, con
 	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y)));
 	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z)));
 	float v000, v100, v010, v110, v001, v101, v011, v111;
-	if (LAYOUT != kLayoutLinear) {
+	if (LAYOUT == kLayoutRunY) {                         // elements are (x,z) neighbourhoods, the two words are rows y and y+1
+		v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v001 = (float) ((f.w0 >> 16) & 0xffu); v101 = (float) (f.w0 >> 24);
+		v010 = (float) (f.w1 & 0xffu); v110 = (float) ((f.w1 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
+	} else if (LAYOUT != kLayoutLinear) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
 			v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v010 = (float) ((f.w0 >> 16) & 0xffu); v110 = (float) (f.w0 >> 24);
 			v001 = (float) (f.w1 & 0xffu); v101 = (float) ((f.w1 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
@@ -449,16 +454,18 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		const uint32_t t = threadIdx.x;
 		// entry j of a table belongs to cell clamp(j - kLutPad, 0, dim - 1): the pad entries repeat the edge cells
 		auto cell_of = [](uint32_t j, uint32_t n) { const int c = (int) j - kLutPad; return (uint32_t) (c < 0 ? 0 : (c > (int) n - 1 ? (int) n - 1 : c)); };
-		if (kUseLut && LAYOUT == kLayoutRun) {
-			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
-			const uint64_t slab = (uint64_t) a.nbx * a.nby * kRunBrickBytes;                  // bricks: x fastest, then y, then z
-			for (uint32_t j = t; j < nz + 2 * kLutPad; j += kThreads) {
-				const uint32_t i = cell_of(j, nz);
+		if (kUseLut && is_run_layout(LAYOUT)) {
+			// r = the run axis (z, or y for kLayoutRunY), o = the other column axis (y, or z); bricks: x fastest, then o, then r
+			const uint32_t nx = a.dim_x, nr = LAYOUT == kLayoutRunY ? a.dim_y : a.dim_z, no = LAYOUT == kLayoutRunY ? a.dim_z : a.dim_y;
+			const uint32_t nbo = LAYOUT == kLayoutRunY ? a.nbz : a.nby;
+			const uint64_t slab = (uint64_t) a.nbx * nbo * kRunBrickBytes;
+			for (uint32_t j = t; j < nr + 2 * kLutPad; j += kThreads) {
+				const uint32_t i = cell_of(j, nr);
 				const uint64_t z0 = (uint64_t) (uintptr_t) vol + (i >> 3) * slab + (i & 7u) * 4u;
 				lut[2 * j] = (uint32_t) z0; lut[2 * j + 1] = (uint32_t) (z0 >> 32);
 			}
 			for (uint32_t j = t; j < nx + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, nx); lut[L::x_at + j] = (i >> 3) * kRunBrickBytes + run_cell_spread(0, i & 7u); }
-			for (uint32_t j = t; j < ny + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, ny); lut[L::y_at + j] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u); }
+			for (uint32_t j = t; j < no + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, no); lut[L::y_at + j] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u); }
 		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
 			const uint32_t elem = 4u * BPV;                                  // bytes per quad element
@@ -766,7 +773,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				//      follows: the wave skips unpacking, the 7 lerps and everything after them;
 				//  (2) after the interpolation: the same test on tb itself skips the LDS lookups, the shading test and the composite.
 				// pinned below the issue (see the NEAREST loop), on the slot's own registers: waits only for the slot's loads
-				if (kManaged && LAYOUT == kLayoutRun) {                // one 8-byte gather per slot: kDepth younger ones may be in flight
+				if (kManaged && is_run_layout(LAYOUT)) {               // one 8-byte gather per slot: kDepth younger ones may be in flight
 					pin(cur.q); managed_wait<kDepth>(); pin(cur.q);
 					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32);
 				} else if (kManaged) {                                 // two 4-byte gathers per slot: 2 * kDepth younger ones
@@ -816,7 +823,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			while (live != 0ull)
 				static_for<0, kSlots>(step_sample);
 			if (kManaged) {                                            // nothing in flight into registers we release
-				auto pin_slot = [&](auto j) { if (LAYOUT == kLayoutRun) pin(f[j.value].q); else pin(f[j.value].w0, f[j.value].w1); };
+				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else pin(f[j.value].w0, f[j.value].w1); };
 				static_for<0, kSlots>(pin_slot);
 				managed_wait<0>();
 				static_for<0, kSlots>(pin_slot);
@@ -854,6 +861,8 @@ static hipError_t launch_sampling(const RayKernelArgs &a, const void *linear, co
 	if constexpr (!nearest && BPV == 1) {
 		if (bricked != nullptr && a.layout == kLayoutRun)
 			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRun>(a, bricked, tf, esl, out, stream);
+		if (bricked != nullptr && a.layout == kLayoutRunY)
+			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRunY>(a, bricked, tf, esl, out, stream);
 	}
 	if (bricked != nullptr) {
 		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
@@ -923,37 +932,45 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint
 	return hipGetLastError();
 }
 
-// linear -> run bricks: one thread per stored element; element k = 8 of a run is the first element of the brick above
-// (slice index clamped at the top face, where the interpolation weight is exactly 0)
+// linear -> run bricks: one thread per stored element; element k = 8 of a run is the first element of the next brick along the run
+// axis (index clamped at the upper face, where the interpolation weight is exactly 0).  RUN_Y = false: runs along z, element =
+// (x,y) neighbourhood of slice z; RUN_Y = true: runs along y, element = (x,z) neighbourhood of row y.
+template <bool RUN_Y>
 __global__ __launch_bounds__(256)
 void brickify_run_kernel(const uint8_t *__restrict__ lin, uint8_t *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
-                         uint32_t nbx, uint32_t nby, uint32_t nbz) {
-	const uint64_t total = (uint64_t) nbx * nby * nbz * 64u * kRunLen;
+                         uint32_t nbx, uint32_t nbo, uint32_t nbr) {
+	const uint32_t dim_o = RUN_Y ? dim_z : dim_y, dim_r = RUN_Y ? dim_y : dim_z;       // other column axis / run axis
+	const uint64_t total = (uint64_t) nbx * nbo * nbr * 64u * kRunLen;
 	const uint64_t stride = (uint64_t) gridDim.x * 256;
 	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
 		const uint64_t brick = o / (64u * kRunLen);
 		const uint32_t in = (uint32_t) (o - brick * (64u * kRunLen)), cell = in / kRunLen, k = in - cell * kRunLen;
-		const uint32_t lx = (cell & 1u) | ((cell >> 1) & 2u) | ((cell >> 2) & 4u), ly = ((cell >> 1) & 1u) | ((cell >> 2) & 2u) | ((cell >> 3) & 4u);
-		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
-		const uint32_t by = br / nbx, bx = br - by * nbx;
-		const uint32_t x = bx * 8u + lx, y = by * 8u + ly;
-		uint32_t z = bz * 8u + k;
+		const uint32_t lx = (cell & 1u) | ((cell >> 1) & 2u) | ((cell >> 2) & 4u), lo = ((cell >> 1) & 1u) | ((cell >> 2) & 2u) | ((cell >> 3) & 4u);
+		const uint32_t br_ = (uint32_t) (brick / ((uint64_t) nbx * nbo)), rest = (uint32_t) (brick - (uint64_t) br_ * nbx * nbo);
+		const uint32_t bo = rest / nbx, bx = rest - bo * nbx;
+		const uint32_t x = bx * 8u + lx, oc = bo * 8u + lo;
+		uint32_t r = br_ * 8u + k;
 		uint8_t q[4] = { 0, 0, 0, 0 };
-		if (x < dim_x && y < dim_y && bz * 8u < dim_z) {
-			if (z > dim_z - 1) z = dim_z - 1;
-			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1;
-			const uint8_t *slice = lin + (uint64_t) z * dim_y * dim_x;
-			q[0] = slice[(uint64_t) y * dim_x + x];  q[1] = slice[(uint64_t) y * dim_x + x1];
-			q[2] = slice[(uint64_t) y1 * dim_x + x]; q[3] = slice[(uint64_t) y1 * dim_x + x1];
+		if (x < dim_x && oc < dim_o && br_ * 8u < dim_r) {
+			if (r > dim_r - 1) r = dim_r - 1;
+			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, o1 = oc + 1 < dim_o ? oc + 1 : dim_o - 1;
+			auto voxel = [&](uint32_t xx, uint32_t oo) {          // (x, other, run) -> (x, y, z)
+				const uint32_t yy = RUN_Y ? r : oo, zz = RUN_Y ? oo : r;
+				return lin[((uint64_t) zz * dim_y + yy) * dim_x + xx];
+			};
+			q[0] = voxel(x, oc); q[1] = voxel(x1, oc); q[2] = voxel(x, o1); q[3] = voxel(x1, o1);
 		}
 		uint8_t *dst = out + o * 4;
 		dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 	}
 }
 
-hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
 	const uint32_t nbx = (dim_x + 7) / 8, nby = (dim_y + 7) / 8, nbz = (dim_z + 7) / 8;
-	hipLaunchKernelGGL(brickify_run_kernel, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	if (run_layout == kLayoutRunY)
+		hipLaunchKernelGGL(brickify_run_kernel<true>, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nbz, nby);
+	else
+		hipLaunchKernelGGL(brickify_run_kernel<false>, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	return hipGetLastError();
 }
 
