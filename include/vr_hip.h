@@ -223,7 +223,8 @@ typedef struct vr_volume_info {
 	uint32_t brick_copies_wanted;   /* copies the layout policy asks for at this size (3: u8 with edges <= 1024, else 1; 0: linear) */
 	uint32_t brick_planes;          /* bit i set = the copy with chunk plane i (0 (x,y), 1 (x,z), 2 (y,z)) is resident */
 	uint32_t linear_resident;       /* 1 while the linear array is in HBM */
-	uint32_t run_copy;              /* run bricks resident (one 8-byte gather per sample): bit 0 runs along z, bit 1 runs along y */
+	uint32_t run_copy;              /* further copies resident: bit 0 run bricks along z, bit 1 run bricks along y (one 8-byte gather per
+	                                   TRILINEAR sample), bit 2 voxel bricks (one voxel per element, what NEAREST reads) */
 	uint64_t linear_bytes, bricked_bytes;
 } vr_volume_info;
 int vr_hip_volume_info(vr_ctx *ctx, vr_volume_info *out);

@@ -72,7 +72,9 @@ def test_hot_kernels_keep_eight_waves_per_simd(vr):
         sampling, bpv, addr, layout = (int(m.group(i)) for i in (2, 3, 4, 5))
         sgprs, vgprs, scratch = int(m.group(6)), int(m.group(7)), int(m.group(8))
         assert scratch == 0, (m.group(1), "spills to scratch")
-        if layout == 1 and addr in (0, 1):
+        if layout in (1, 2, 3, 4) and addr in (0, 1):           # quad bricks, run bricks (z / y), voxel bricks
             found += 1
             assert sgprs <= 80 and vgprs <= 64, (m.group(1), sgprs, vgprs)
-    assert found == 12, found      # {NEAREST, TRILINEAR, TRILINEAR_Q8} x {u8, u16} x {32-bit, 64-bit z tables}
+    # quad bricks {NEAREST, TRILINEAR, Q8} x {u8, u16} x {32-bit, 64-bit z tables} = 12, voxel bricks (NEAREST) x 2 x 2 = 4,
+    # run bricks {z, y} x {TRILINEAR, Q8} (u8, 32-bit) = 4
+    assert found == 20, found

@@ -50,11 +50,14 @@ def test_nearest_address_chain_variants_agree(vr, gpu, golden):
     try:
         for case in [c for c in golden.cases(True) if c["volume"] == "bucky"][::3]:
             for force in (0, 8, 4, 12):
-                gpu.set_wide_addressing(force)
-                out = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
-                assert compare_frames(out, golden.frame(case)) == (0, 0), (case["label"], force)
+                for plane in (-1, 0):            # -1: the voxel bricks (one voxel per element); 0: the (x,y) quad copy
+                    gpu.set_wide_addressing(force)
+                    gpu.set_brick_plane(plane)
+                    out = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+                    assert compare_frames(out, golden.frame(case)) == (0, 0), (case["label"], force, plane)
     finally:
         gpu.set_wide_addressing(False)
+        gpu.set_brick_plane(-1)
 
 
 def test_config2_shell256_hashes(vr, gpu, golden):
@@ -336,7 +339,7 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         info = r.volume_info()
         assert (info.dim_x, info.dim_y, info.dim_z, info.bytes_per_voxel) == (32, 32, 32, 1)
         assert info.layout == vr.LAYOUT_BRICKED and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7
-        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.run_copy == 3 and info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16)
+        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.run_copy == 7 and info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3
         case = [c for c in golden.cases(True) if c["label"] == "bench256_view1_default"][0]
         before = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
         r.release_linear_copy()

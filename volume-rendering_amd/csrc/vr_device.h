@@ -77,8 +77,14 @@ struct RayKernelArgs {
 //                   runs hold rows y .. y+8 of a cell column (x,z).  Same single 8-byte gather; read by the views that march
 //                   mostly along z, for which the runs of kLayoutRun would lie ALONG the march (measured: perspective along z
 //                   2.99 ms with runs along z against 2.47 ms with the quad copy) — runs should lie across it.
-enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3 };
+//   kLayoutVoxel  : "voxel bricks" for NEAREST sampling — ONE voxel per element in the brick order of the (x,y) quad copy.  NEAREST
+//                   needs one voxel per sample; reading it out of a 4-byte quad element moves 4x the bytes and makes a 16-byte
+//                   chunk cover 2x2 cells.  With 1-byte elements a chunk covers 4x4 cells of a slice and a 128-byte line 8x8x2
+//                   voxels: the lane quads of views that are not aligned stay inside one chunk far more often, and the
+//                   compulsory traffic of a frame is the volume itself (1 GiB at 1024^3).
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4 };
 __host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY; }
+__host__ __device__ constexpr bool is_brick_table_layout(int layout) { return layout == (int) kLayoutBricked || layout == (int) kLayoutVoxel; }
 constexpr uint32_t kRunLen = 9, kRunBytes = kRunLen * 4, kRunBrickBytes = 64 * kRunBytes;       // 8x8 cell columns per brick
 // byte offset of cell column (x & 7, y & 7) inside a run brick: 2-D Morton order, 36-byte runs
 __host__ __device__ inline uint32_t run_cell_spread(uint32_t axis, uint32_t v) {
@@ -125,6 +131,9 @@ inline uint64_t volume_tail_slack(uint32_t dim_x, uint32_t dim_y) { return (uint
 // linear -> quad-brick copy
 hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per_voxel, uint32_t plane, uint32_t dim_x, uint32_t dim_y,
                            uint32_t dim_z, hipStream_t stream);
+// linear -> voxel bricks (NEAREST): element (x,y,z) = the voxel, brick order of the (x,y) quad copy
+hipError_t launch_brickify_voxel(const void *linear, void *voxel_bricks, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                                 hipStream_t stream);
 // linear -> run bricks (1-byte voxels)
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout /* kLayoutRun | kLayoutRunY */, uint32_t dim_x, uint32_t dim_y,
                                uint32_t dim_z, hipStream_t stream);

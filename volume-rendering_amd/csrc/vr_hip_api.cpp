@@ -43,6 +43,7 @@ struct vr_ctx {
 	void *vol_plane[kPlanes] = { nullptr, nullptr, nullptr };   // [0] = vol_bricked; [1], [2]: chunk planes (x,z), (y,z) — u8, edges <= 1024
 	void *vol_run = nullptr;                // run bricks (vr_device.h kLayoutRun, runs along z): one 8-byte gather per sample
 	void *vol_run_y = nullptr;              // run bricks with the runs along y (kLayoutRunY): for views that march mostly along z
+	void *vol_near = nullptr;               // voxel bricks (kLayoutVoxel): one voxel per element, what NEAREST sampling reads
 	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
 	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
 	uint32_t layout = VR_LAYOUT_BRICKED;
@@ -309,6 +310,9 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		else if (plane == kPlanes + 1 && c->vol_run_y) a.layout = kLayoutRunY;
 		if (run_candidate && c->vol_run) a.layout = run_layout;
 	}
+	// NEAREST: the voxel bricks (one voxel per element) unless a quad copy is forced (testing) or a 64-bit path is
+	if (p->sampling == VR_SAMPLE_NEAREST && a.layout == kLayoutBricked && c->vol_near && c->brick_plane_force < 0 && c->force_wide != 1)
+		a.layout = kLayoutVoxel;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
 	{   // RaycasterBase.h:59-63: index / esl_block_dims, prepared as shift or multiply-high
@@ -339,6 +343,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 	if (a.layout == kLayoutRun) brick_copy = c->vol_run;
 	else if (a.layout == kLayoutRunY) brick_copy = c->vol_run_y;
+	else if (a.layout == kLayoutVoxel) brick_copy = c->vol_near;
 	else if (a.layout == kLayoutBricked) brick_copy = c->vol_plane[a.brick_plane];
 
 	EventPair &ev = c->ring[c->ring_head];
@@ -361,6 +366,7 @@ void free_bricks(vr_ctx *c) {
 	for (uint32_t i = 0; i < kPlanes; i++) if (c->vol_plane[i]) { (void) hipFree(c->vol_plane[i]); c->vol_plane[i] = nullptr; }
 	if (c->vol_run) { (void) hipFree(c->vol_run); c->vol_run = nullptr; }
 	if (c->vol_run_y) { (void) hipFree(c->vol_run_y); c->vol_run_y = nullptr; }
+	if (c->vol_near) { (void) hipFree(c->vol_near); c->vol_near = nullptr; }
 	c->vol_bricked = nullptr;
 }
 
@@ -396,6 +402,15 @@ int finalize_volume(vr_ctx *c) {
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) break;
 		if (hipMalloc(&c->vol_plane[plane], bytes) != hipSuccess) { c->vol_plane[plane] = nullptr; (void) hipGetLastError(); break; }
 		VR_TRY(c, launch_brickify(c->vol, c->vol_plane[plane], c->bpv, plane, c->dim[0], c->dim[1], c->dim[2], c->stream));
+	}
+	// the voxel bricks NEAREST sampling reads (a quarter of a quad copy): wherever the address tables reach
+	if (max_dim <= 2048u) {
+		const uint64_t near_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && near_bytes < free_b && free_b - near_bytes >= total_b / 2) {
+			if (hipMalloc(&c->vol_near, near_bytes) != hipSuccess) { c->vol_near = nullptr; (void) hipGetLastError(); }
+			else VR_TRY(c, launch_brickify_voxel(c->vol, c->vol_near, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream));
+		}
 	}
 	// the run bricks for views that are not along an axis: same conditions (1-byte voxels, table-addressable edges, spare HBM)
 	if (c->bpv == 1 && max_dim <= 1024u) {
@@ -687,6 +702,7 @@ int vr_hip_volume_info(vr_ctx *c, vr_volume_info *out) {
 		if (c->vol_plane[i]) { out->brick_planes |= 1u << i; out->brick_copies++; out->bricked_bytes += copy_bytes; }
 	if (c->vol_run) { out->run_copy |= 1u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
 	if (c->vol_run_y) { out->run_copy |= 2u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
+	if (c->vol_near) { out->run_copy |= 4u; out->bricked_bytes += bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv; }
 	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? ((c->bpv == 1 && std::max(c->dim[0], std::max(c->dim[1], c->dim[2])) <= 1024u && copy_bytes <= (1ull << 32)) ? 3u : 1u) : 0u;
 	return VR_OK;
 }

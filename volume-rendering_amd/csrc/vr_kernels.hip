@@ -79,10 +79,13 @@ template <> struct VoxelT<2> { typedef uint16_t type; };
 // Only the hot instantiations use them (1-byte voxels, 32-bit table addressing, the quad or run bricks); the loop drains them
 // with s_waitcnt vmcnt(0) before it lets go of the destination registers.
 template <int BPV, int ADDR, int LAYOUT> struct Managed {
-	static constexpr bool value = BPV == 1 && ADDR == kAddr32 && (LAYOUT == kLayoutBricked || is_run_layout(LAYOUT));
+	static constexpr bool value = BPV == 1 && ADDR == kAddr32 && (is_brick_table_layout(LAYOUT) || is_run_layout(LAYOUT));
 };
 __device__ __forceinline__ void managed_load32(uint32_t &dst, uint32_t byte_offset, const void *base) {
 	asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
+}
+__device__ __forceinline__ void managed_load8(uint32_t &dst, uint32_t byte_offset, const void *base) {       // zero-extended byte
+	asm volatile("global_load_ubyte %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
 }
 __device__ __forceinline__ void managed_load64(uint64_t &dst, uint64_t address) {      // split into halves only AFTER the wait
 	asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(address));
@@ -95,14 +98,15 @@ template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
                                                 int ix, int iy, int iz) {
 	typedef typename VoxelT<BPV>::type V;
-	if (LAYOUT == kLayoutBricked) {
+	if (is_brick_table_layout(LAYOUT)) {
 		typedef LutCfg<ADDR> L;                      // table lookups take indices -kLutPad .. dim - 1 + kLutPad
 		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
 		const uint8_t *q;
 		if (ADDR == kAddr32) {
 			if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 				uint32_t word;
-				managed_load32(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
+				if (LAYOUT == kLayoutVoxel) managed_load8(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
+				else managed_load32(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
 				return word;
 			}
 			q = (const uint8_t *) vol + (exy + lut[(int) L::z_words * (iz + kLutPad)]);
@@ -113,6 +117,7 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 		// the RAW element word: the voxel is its low byte / half (voxel_of).  Masking here would hand the compiler an operation on the
 		// loaded value that it hoists to the loop latch of the software-pipelined march — behind an s_waitcnt vmcnt(0) that drains
 		// every prefetch once per iteration (measured: the NEAREST full march was latency bound because of it).
+		if (LAYOUT == kLayoutVoxel) return *(const V *) q;           // voxel bricks: the element IS the voxel
 		return *(const uint32_t *) q;
 	}
 	if (ADDR == kAddrWide) {
@@ -144,7 +149,7 @@ __device__ __forceinline__ uint32_t sample_nearest(const void *vol, const RayKer
 template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ uint32_t sample_nearest_incube(const void *vol, const RayKernelArgs &a, const uint32_t *lut, f3 pos) {
 	int iz = (int) ((pos.z + 1) * a.half_z), iy = (int) ((pos.y + 1) * a.half_y), ix = (int) ((pos.x + 1) * a.half_x);
-	if (!(LAYOUT == kLayoutBricked && ADDR != kAddrWide)) {             // no tables: clamp the index at the upper face
+	if (!(is_brick_table_layout(LAYOUT) && ADDR != kAddrWide)) {        // no tables: clamp the index at the upper face
 		const int mz = (int) a.dim_z - 1, my = (int) a.dim_y - 1, mx = (int) a.dim_x - 1;
 		ix = ix < mx ? ix : mx; iy = iy < my ? iy : my; iz = iz < mz ? iz : mz;
 	}
@@ -468,7 +473,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			for (uint32_t j = t; j < no + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, no); lut[L::y_at + j] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u); }
 		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
-			const uint32_t elem = 4u * BPV;                                  // bytes per quad element
+			const uint32_t elem = LAYOUT == kLayoutVoxel ? BPV : 4u * BPV;   // bytes per element: a quad of voxels, or one voxel
 			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
 			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t jj = t; jj < nz + 2 * kLutPad; jj += kThreads) {
@@ -636,7 +641,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
 		uint64_t live = __builtin_amdgcn_ballot_w64(alive);            // liveness as one scalar wave mask (see TRILINEAR)
 		if (!alive) { kx = 0.0f; ky = 0.0f; origin = mk3(0.0f, 0.0f, 0.0f); dir = origin; pt = origin; }
-		constexpr bool kTables = LAYOUT == kLayoutBricked && ADDR != kAddrWide;       // padded address tables (kLutPad)
+		constexpr bool kTables = is_brick_table_layout(LAYOUT) && ADDR != kAddrWide;  // padded address tables (kLutPad)
 		auto march = [&](auto clamp_tag, auto scaled_tag) {
 		constexpr bool kClamp = decltype(clamp_tag)::value;
 		// kFree: fetch positions are NOT pulled back to the ray's segment — a finished lane's k simply stops (its step becomes 0, a
@@ -864,6 +869,13 @@ static hipError_t launch_sampling(const RayKernelArgs &a, const void *linear, co
 		if (bricked != nullptr && a.layout == kLayoutRunY)
 			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRunY>(a, bricked, tf, esl, out, stream);
 	}
+	if constexpr (nearest) {
+		if (bricked != nullptr && a.layout == kLayoutVoxel) {
+			if (max_dim <= LutCfg<kAddr32>::max_dim && a.force_wide != 2)
+				return launch_variant<SAMPLING, BPV, kAddr32, kLayoutVoxel>(a, bricked, tf, esl, out, stream);
+			return launch_variant<SAMPLING, BPV, kAddrLut64, kLayoutVoxel>(a, bricked, tf, esl, out, stream);
+		}
+	}
 	if (bricked != nullptr) {
 		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
 		if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
@@ -929,6 +941,32 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint
 	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
 	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	return hipGetLastError();
+}
+
+// linear -> voxel bricks: element o of the (x,y)-plane brick order holds the voxel itself (zero outside the volume)
+template <int BPV>
+__global__ __launch_bounds__(256)
+void brickify_voxel_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                           uint32_t nbx, uint32_t nby, uint32_t nbz) {
+	typedef typename VoxelT<BPV>::type V;
+	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+		const uint64_t brick = o / kBrickPitch;
+		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
+		const uint32_t lz = brick_collect(BPV, kPlaneXY, 2, local), lx = brick_collect(BPV, kPlaneXY, 0, local), ly = brick_collect(BPV, kPlaneXY, 1, local);
+		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
+		const uint32_t by = br / nbx, bx = br - by * nbx;
+		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
+		((V *) out)[o] = (x < dim_x && y < dim_y && z < dim_z) ? ((const V *) lin)[((uint64_t) z * dim_y + y) * dim_x + x] : (V) 0;
+	}
+}
+
+hipError_t launch_brickify_voxel(const void *linear, void *voxel_bricks, uint32_t bpv, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge, nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
+	if (bpv == 1) hipLaunchKernelGGL(brickify_voxel_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, voxel_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	else          hipLaunchKernelGGL(brickify_voxel_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, voxel_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	return hipGetLastError();
 }
 
