@@ -639,6 +639,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// segment inside the cube (for live lanes that IS the sample position); lanes without a segment march position 0.
 		// clamp_fetch (far-away views, see TRILINEAR) falls back to the reference's two-sided clamp.
 		const int tf_zero_idx = (int) a.tf_zero_below;                 // entries 0..tf_zero_idx are (0,0,0,0)
+		const int opaque_above = (tf_zero_idx + 1) * VR_TF_RATIO * (BPV == 1 ? 1 : 256) - 1;
 		uint64_t live = __builtin_amdgcn_ballot_w64(alive);            // liveness as one scalar wave mask (see TRILINEAR)
 		if (!alive) { kx = 0.0f; ky = 0.0f; origin = mk3(0.0f, 0.0f, 0.0f); dir = origin; pt = origin; }
 		constexpr bool kTables = is_brick_table_layout(LAYOUT) && ADDR != kAddrWide;  // padded address tables (kLutPad)
@@ -679,8 +680,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			if (kManaged) { pin(word[c]); managed_wait<kDepth>(); pin(word[c]); }
 			else pin(word[c]);
 			const uint32_t s = voxel_of<BPV, LAYOUT>(word[c]);
-			const uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;                          // CPURenderer.cpp:31
-			if ((__builtin_amdgcn_sicmp((int) idx, tf_zero_idx, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+			// transfer_fn[sample / TF_RATIO] (CPURenderer.cpp:31) is (0,0,0,0) for index <= tf_zero_idx, i.e. for
+			// s <= opaque_above = (tf_zero_idx + 1) * TF_RATIO * (1 or 256) - 1: tested on the voxel itself, the index is only formed
+			// by the few samples that get past the test
+			if ((__builtin_amdgcn_sicmp((int) s, opaque_above, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+				uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;
+				asm volatile("" : "+v"(idx));                                                       // keep the index arithmetic inside the branch
 				f4 cur = lds.tf[idx];
 				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
 				if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
@@ -853,7 +858,15 @@ static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, 
 	RayKernelArgs a = args;
 	a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
 	a.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
-	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), 0, stream,
+	// Run-brick frames are launched with 16 KiB of unused dynamic LDS: 3 instead of 4 workgroups per CU (24 waves).  Their waves
+	// touch ~10 cache lines per step, 32 of them overflow the 256 lines of the 32 KiB L1 between two steps and the L2 catches only a
+	// quarter of that reuse (measured: fabric requests -11 %, frame time -2 ... -5 % on those views; the VALU-bound quad-brick views
+	// need all 32 waves and lose 10 % with the same padding).  VR_RUN_LDS_PAD=0 builds without it (A/B).
+#ifndef VR_RUN_LDS_PAD
+#define VR_RUN_LDS_PAD 16384
+#endif
+	const uint32_t dynamic_lds = is_run_layout(LAYOUT) ? VR_RUN_LDS_PAD : 0;
+	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
 }
