@@ -382,8 +382,8 @@ def run_rank(a):
                 "traffic": traffic.get("bytes_per_launch"), "traffic_commit": traffic.get("commit"),
                 "traffic_kernel_ms": traffic.get("kernel_ms"),
                 "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernel_instantiations": "raymarch_kernel<sampling,1,0,1> (quad bricks: views along a volume axis) and <sampling,1,0,2> (run bricks: "
-                                         "every other view); kernel_ms = hipEvent mean over ALL timed launches of both",
+                "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
+                                         "(every other TRILINEAR view), 4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
                 "note": "full march is gather / VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "

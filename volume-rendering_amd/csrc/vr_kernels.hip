@@ -861,11 +861,13 @@ static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, 
 	// Run-brick frames are launched with 16 KiB of unused dynamic LDS: 3 instead of 4 workgroups per CU (24 waves).  Their waves
 	// touch ~10 cache lines per step, 32 of them overflow the 256 lines of the 32 KiB L1 between two steps and the L2 catches only a
 	// quarter of that reuse (measured: fabric requests -11 %, frame time -2 ... -5 % on those views; the VALU-bound quad-brick views
-	// need all 32 waves and lose 10 % with the same padding).  VR_RUN_LDS_PAD=0 builds without it (A/B).
+	// need all 32 waves and lose 10 % with the same padding).  Not with empty-space leaping: those rays are short, the frame time is
+	// the tail of the few waves that probe a whole row of blocks, and fewer resident workgroups lengthen it (view 3: 1.53 -> 2.16 ms).
+	// VR_RUN_LDS_PAD=0 builds without it (A/B).
 #ifndef VR_RUN_LDS_PAD
 #define VR_RUN_LDS_PAD 16384
 #endif
-	const uint32_t dynamic_lds = is_run_layout(LAYOUT) ? VR_RUN_LDS_PAD : 0;
+	const uint32_t dynamic_lds = is_run_layout(LAYOUT) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
 	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
