@@ -867,7 +867,10 @@ static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, 
 #ifndef VR_RUN_LDS_PAD
 #define VR_RUN_LDS_PAD 16384
 #endif
-	const uint32_t dynamic_lds = is_run_layout(LAYOUT) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
+	#ifndef VR_PAD_LAYOUTS
+#define VR_PAD_LAYOUTS ((1u << kLayoutRun) | (1u << kLayoutRunY))
+#endif
+	const uint32_t dynamic_lds = ((VR_PAD_LAYOUTS >> LAYOUT) & 1u) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
 	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
 	                   a, volume, tf, esl, (uint32_t *) out);
 	return hipGetLastError();
