@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k(const uint8_t *buf, uint32_t *out, int 
 		for (int u = 0; u < 8; u++) {
 			const uint8_t *p = buf + off + walk + u * 128 * 1024;
 			if (W == 4) acc ^= *(const uint32_t *) p;
+			else if (W == 16) { const uint4 v = *(const uint4 *) p; acc ^= v.x ^ v.y ^ v.z ^ v.w; }   // global_load_dwordx4, 8-byte aligned (2-byte voxels)
 			else { const uint2 v = *(const uint2 *) p; acc ^= v.x ^ v.y; }     // global_load_dwordx2; the address may be only 4-byte aligned
 		}
 		walk = (walk + 8192) & 16383;   // stays inside this wave's 16 KiB window
@@ -61,9 +62,9 @@ int main() {
 		{ "oblique (-45,-45), 0.5 cell/px, 4x1 quads", 1, 0.5f, 0, 0.3f },
 		{ "oblique (-45,-45), 0.5 cell/px, 2x2 quads", 1, 0.5f, 2, 0.3f },
 	};
-	printf("%-64s %9s %9s %9s %9s %9s\n", "pattern (ns per wave-instruction per CU)", "quad c", "quad c+1", "run8 x2", "run9 x2", "run8 al8");
+	printf("%-64s %9s %9s %9s %9s %9s %9s %9s\n", "pattern (ns per wave-instruction per CU)", "quad c", "quad c+1", "run8 x2", "run9 x2", "run8 al8", "u16 quad", "u16 run9");
 	for (const Pat &p : pats) for (int cstep = 0; cstep < 2; cstep++) {
-		uint32_t hr9[64], hr8a[64];
+		uint32_t hr9[64], hr8a[64], hq16[64], hr16[64];          // 2-byte voxels: 8-byte quad elements (two loads per sample), 72-byte runs (one 16-byte load)
 		for (int l = 0; l < 64; l++) {
 			const int qd = l >> 4;
 			int gu = l & 3, gv = (l >> 2) & 3;
@@ -84,11 +85,13 @@ int main() {
 			if ((ic & 7) == 7) hr[l] -= 4;
 			hr9[l] = brick * 2304 + mort2(ia & 7, ib & 7) * 36 + (ic & 7) * 4;         // run of 9
 			hr8a[l] = brick * 2048 + mort2(ia & 7, ib & 7) * 32 + (ic & 6) * 4;        // 8-byte aligned (even c only)
+			hq16[l] = (brick * 512 + (spread(ia & 7, 0) | spread(ib & 7, 1) | spread(ic & 7, 2))) * 8;
+			hr16[l] = brick * 4608 + mort2(ia & 7, ib & 7) * 72 + (ic & 7) * 8;
 		}
 		char name[160];
 		snprintf(name, sizeof name, "%s, c&7=%d", p.name, cstep ? 3 : 6);
-		printf("%-64s %9.2f %9.2f %9.2f %9.2f %9.2f\n", name, run<4>(buf, out, d_off, hq0), run<4>(buf, out, d_off, hq1),
-		       run<8>(buf, out, d_off, hr), run<8>(buf, out, d_off, hr9), run<8>(buf, out, d_off, hr8a));
+		printf("%-64s %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f\n", name, run<4>(buf, out, d_off, hq0), run<4>(buf, out, d_off, hq1),
+		       run<8>(buf, out, d_off, hr), run<8>(buf, out, d_off, hr9), run<8>(buf, out, d_off, hr8a), run<8>(buf, out, d_off, hq16), run<16>(buf, out, d_off, hr16));
 	}
 	return 0;
 }

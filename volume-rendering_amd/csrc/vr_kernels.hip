@@ -87,6 +87,10 @@ __device__ __forceinline__ void managed_load32(uint32_t &dst, uint32_t byte_offs
 __device__ __forceinline__ void managed_load8(uint32_t &dst, uint32_t byte_offset, const void *base) {       // zero-extended byte
 	asm volatile("global_load_ubyte %0, %1, %2" : "=v"(dst) : "v"(byte_offset), "s"(base));
 }
+// TRILINEAR with 2-byte voxels: the two 8-byte elements of a quad-brick sample, by 64-bit address (copies beyond 4 GiB included)
+template <int BPV, int ADDR, int LAYOUT> struct ManagedTri {
+	static constexpr bool value = Managed<BPV, ADDR, LAYOUT>::value || (BPV == 2 && LAYOUT == kLayoutBricked && (ADDR == kAddr32 || ADDR == kAddrLut64));
+};
 __device__ __forceinline__ void managed_load64(uint64_t &dst, uint64_t address) {      // split into halves only AFTER the wait
 	asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(address));
 }
@@ -181,6 +185,7 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	// linear : the four x-pairs (y,z) (y+1,z) (y,z+1) (y+1,z+1)
 	uint32_t w0, w1, w2, w3;
 	uint64_t q;                                      // run bricks, managed load: both slices as ONE 64-bit destination (w0 = low, w1 = high)
+	uint64_t q2;                                     // 2-byte voxels, managed loads: q = the element of slice z (w0, w1), q2 = of slice z+1 (w2, w3)
 };
 
 // `clamp` (wave-uniform) = false is allowed for positions INSIDE the volume's cube, i.e. coordinates in (-1, N): there
@@ -191,7 +196,7 @@ template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
                                                            float xb, float yb, float zb, bool clamp) {
 	TriFetch<BPV, LAYOUT> f;
-	f.q = 0;
+	f.q = 0; f.q2 = 0;
 	if (clamp) {
 		xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
 		yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
@@ -243,6 +248,9 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		} else if (BPV == 1) {                           // 2 x global_load_dword, 4-byte aligned
 			f.w0 = *(const uint32_t *) q0;
 			f.w1 = *(const uint32_t *) q1;
+		} else if (MANAGED && ManagedTri<BPV, ADDR, LAYOUT>::value) {
+			managed_load64(f.q, (uint64_t) (uintptr_t) q0);
+			managed_load64(f.q2, (uint64_t) (uintptr_t) q1);
 		} else {                                         // 2 x global_load_dwordx2, 8-byte aligned
 			const uint2 lo = *(const uint2 *) q0, hi = *(const uint2 *) q1;
 			f.w0 = lo.x; f.w1 = lo.y; f.w2 = hi.x; f.w3 = hi.y;
@@ -426,6 +434,7 @@ __device__ __forceinline__ void pin(uint32_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(uint32_t &x, uint32_t &y) { asm volatile("" : "+v"(x), "+v"(y)); }
 __device__ __forceinline__ void pin(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) { asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w)); }
 __device__ __forceinline__ void pin(uint64_t &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(uint64_t &x, uint64_t &y) { asm volatile("" : "+v"(x), "+v"(y)); }
 template <int I> __device__ __forceinline__ void managed_wait() {       // s_waitcnt vmcnt(I): all but the I youngest gathers have landed
 	static_assert(I >= 0 && I <= 15, "vmcnt");
 	if constexpr (I == 0) asm volatile("s_waitcnt vmcnt(0)"); else if constexpr (I == 1) asm volatile("s_waitcnt vmcnt(1)");
@@ -747,7 +756,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				if (!kClamp && !kFree) k = __builtin_fminf(k, ky);
 				return tri_issue<BPV, ADDR, LAYOUT, true>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
 			};
-			constexpr bool kManaged = Managed<BPV, ADDR, LAYOUT>::value;
+			constexpr bool kManaged = ManagedTri<BPV, ADDR, LAYOUT>::value;
 			const uint64_t skip_never = a.skip_never ? ~0ull : 0ull;
 			// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
 			// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
@@ -759,7 +768,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			constexpr int kDepth = BPV == 1 ? vr::kDepth : (vr::kDepth > 1 ? vr::kDepth - 1 : 1), kSlots = kDepth + 1;
 			TriFetch<BPV, LAYOUT> f[kSlots]; float ks[kSlots];
 			ks[0] = kx;
-			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0;
+			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0; f[kSlots - 1].q2 = 0;
 			static_for<0, kDepth>([&](auto j) {
 				if constexpr (j.value > 0) ks[j.value] = ks[j.value - 1] + step_v;
 				f[j.value] = issue(ks[j.value]);
@@ -786,6 +795,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				if (kManaged && is_run_layout(LAYOUT)) {               // one 8-byte gather per slot: kDepth younger ones may be in flight
 					pin(cur.q); managed_wait<kDepth>(); pin(cur.q);
 					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32);
+				} else if (kManaged && BPV == 2) {                     // two 8-byte gathers per slot (2-byte voxels)
+					pin(cur.q, cur.q2); managed_wait<2 * kDepth>(); pin(cur.q, cur.q2);
+					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32); cur.w2 = (uint32_t) cur.q2; cur.w3 = (uint32_t) (cur.q2 >> 32);
 				} else if (kManaged) {                                 // two 4-byte gathers per slot: 2 * kDepth younger ones
 					pin(cur.w0, cur.w1); managed_wait<2 * kDepth>(); pin(cur.w0, cur.w1);
 				} else if (LAYOUT != kLayoutLinear && BPV == 1) pin(cur.w0, cur.w1);
@@ -833,7 +845,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			while (live != 0ull)
 				static_for<0, kSlots>(step_sample);
 			if (kManaged) {                                            // nothing in flight into registers we release
-				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else pin(f[j.value].w0, f[j.value].w1); };
+				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else if (BPV == 2) pin(f[j.value].q, f[j.value].q2); else pin(f[j.value].w0, f[j.value].w1); };
 				static_for<0, kSlots>(pin_slot);
 				managed_wait<0>();
 				static_for<0, kSlots>(pin_slot);
