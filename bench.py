@@ -391,6 +391,20 @@ def run_rank(a):
             out["minmax_feeder"] = {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
                                     "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),
                                     "frac_of_hbm_peak": round(n ** 3 / (minmax_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if world == 1:
+                # one launch per benchmark view, outside the timed region: the per-view kernel times behind the mean above
+                per_view = []
+                for v in views:
+                    p_v = split.apply(scene.frame_params(v, sampling))
+                    r.render_volume_device(p_v, local[0].data_ptr(), stream)
+                    render_stream.synchronize()
+                    r.timing_reset()
+                    for _ in range(3):
+                        r.render_volume_device(p_v, local[0].data_ptr(), stream)
+                    render_stream.synchronize()
+                    tv = r.timing()
+                    per_view.append(round(tv.kernel_ms_sum / max(1, tv.launches), 4))
+                out["roofline"]["per_view_kernel_ms"] = per_view
             if not a.no_extras and world == 1:
                 out["extras"] = extras(vr, r, scene, views, split, local[0], stream, render_stream, n, W, H)
                 set_mode(scene, a.mode)
