@@ -396,10 +396,11 @@ def run_rank(a):
                 per_view = []
                 for v in views:
                     p_v = split.apply(scene.frame_params(v, sampling))
-                    r.render_volume_device(p_v, local[0].data_ptr(), stream)
+                    for _ in range(2):
+                        r.render_volume_device(p_v, local[0].data_ptr(), stream)
                     render_stream.synchronize()
                     r.timing_reset()
-                    for _ in range(3):
+                    for _ in range(4):
                         r.render_volume_device(p_v, local[0].data_ptr(), stream)
                     render_stream.synchronize()
                     tv = r.timing()
