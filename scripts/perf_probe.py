@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--layout", default="bricked")
     ap.add_argument("--bpv", type=int, default=1, help="bytes per voxel of the generated volume")
     ap.add_argument("--tile-map", default="", help="lane_map,phase_x,phase_y (default: automatic)")
-    ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz")
+    ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz, 3 / 4 run bricks along z / y")
+    ap.add_argument("--wide", type=int, default=0, help="vr_hip_set_wide_addressing value (2: 64-bit z tables, 1024-thread workgroups)")
     a = ap.parse_args()
     vr = importlib.import_module("volume-rendering_amd")
     r = vr.HipRenderer(0)
     r.set_layout(vr.LAYOUT_BRICKED if a.layout == "bricked" else vr.LAYOUT_LINEAR)
     r.set_brick_plane(a.plane)
+    if a.wide:
+        r.set_wide_addressing(a.wide)
     if a.tile_map:
         r.set_tile_mapping(*[int(x) for x in a.tile_map.split(",")])
     n, W = a.volume, a.viewport
