@@ -1,6 +1,6 @@
 """Randomised parity: random volumes (odd dimensions, u8 / u16), random transfer functions, random views (camera inside
 and outside the cube, axis-aligned directions with exact zeros, orthogonal and perspective), random ray step / threshold /
-light / ESL — the HIP path must equal the CPU oracle bit for bit in both sampling modes and both layouts."""
+light / ESL — the HIP path must equal the CPU oracle bit for bit in all three sampling modes and both layouts."""
 import os
 
 import numpy as np
@@ -78,8 +78,8 @@ def test_random_scenes_match_oracle(vr, gpu, oracle):
             gpu.set_wide_addressing({4: 1, 3: 2, 2: 8}.get(scene_i % 5, 0))     # + 8: no scaled-domain NEAREST
             gpu.set_transfer_fn(tf, esl)
             gpu.set_volume(vox)
-            for _ in range(6):
-                for sampling in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+            for frame_i in range(6):
+                for sampling in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR if frame_i % 2 == 0 else vr.SAMPLE_TRILINEAR_Q8):
                     p = random_params(rng, vr, bd, bs, ray_step, sampling)
                     out = gpu.render_volume(p)
                     ref = oracle.render(p, vox, tf, esl, threads=4)
