@@ -53,8 +53,10 @@ typedef enum vr_sampling {
 	                             fractional value"): what the texture unit of renderer 4 computes, as far as it is specified */
 } vr_sampling;
 
-/* How the TRILINEAR path keeps the volume in HBM (NEAREST always reads the reference's linear array).
- * Both layouts give bit-identical images; the choice is speed only. */
+/* How the render paths keep the volume in HBM.  VR_LAYOUT_LINEAR: every sampling mode reads the reference's linear array.
+ * VR_LAYOUT_BRICKED (default): TRILINEAR reads quad or run bricks, NEAREST reads voxel bricks (one voxel per element in brick
+ * order) — copies built from the linear array on first use (vr_hip_prepare builds them ahead of time).
+ * All layouts give bit-identical images; the choice is speed only. */
 typedef enum vr_layout {
 	VR_LAYOUT_LINEAR  = 0,    /* x-fastest linear array exactly as Model::data (ModelBase.h:18-22) */
 	VR_LAYOUT_BRICKED = 1     /* default: "quad bricks" — every element packs the 2x2 (x,y) voxel neighbourhood of a slice into
@@ -209,13 +211,35 @@ int  vr_hip_multi_timing(vr_multi *m, float *per_device_kernel_ms, float *total_
 void vr_hip_multi_band_map(uint32_t n, uint32_t band_rows, uint32_t y, uint32_t *rank_out, uint32_t *local_row_out);
 uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
 
+/* ---- brick copies: built lazily, or ahead of time ----
+ * With VR_LAYOUT_BRICKED a frame reads one of up to six copies of the volume, chosen per frame from the sampling mode and the
+ * view (volume-rendering_amd/csrc/vr_device.h).  set_volume only uploads the linear array; a copy is built (one kernel, 6-8 ms at
+ * 1024^3, the context's stream, synchronous) by the first frame that wants it, so a NEAREST-only session holds the linear array
+ * + the voxel bricks and nothing else.  vr_hip_prepare builds the copies named by `copies` (VR_COPY_* bits) now — what a
+ * benchmark, or a caller about to vr_hip_release_linear_copy, does.  Copies the layout policy does not have at this volume
+ * size (the second / third quad plane and the run bricks need 1-byte voxels and edges <= 1024; voxel bricks edges <= 2048) are
+ * skipped silently; every copy but the first quad copy is refused (VR_ERR_ALLOC) unless half of the HBM stays free — frames then
+ * read the next best copy, see vr_volume_info::copies_refused.  No reference counterpart (GPURenderer4 builds its one cudaArray
+ * in set_volume, GPURenderer4.cu:123-141). */
+#define VR_COPY_QUAD_XY  (1u << 0)   /* quad bricks, 16-byte chunks in the (x,y) plane: TRILINEAR views along z (and every fallback) */
+#define VR_COPY_QUAD_XZ  (1u << 1)   /* ... (x,z) plane: orthogonal views along y */
+#define VR_COPY_QUAD_YZ  (1u << 2)   /* ... (y,z) plane: orthogonal views along x */
+#define VR_COPY_RUN_Z    (1u << 3)   /* run bricks along z: TRILINEAR views that cannot be chunk-aligned, marching mostly along x or y */
+#define VR_COPY_RUN_Y    (1u << 4)   /* run bricks along y: the same, marching mostly along z */
+#define VR_COPY_VOXEL    (1u << 5)   /* voxel bricks: NEAREST */
+#define VR_COPY_ALL      0x3fu
+#define VR_COPY_KINDS    6
+int vr_hip_prepare(vr_ctx *ctx, uint32_t copies);
+
 /* ---- what the resident volume occupies in HBM, and giving some of it back ----
- * The bricked layout keeps the reference's linear array (feeders, download, rebuilding copies) next to one brick copy per chunk
- * plane; the second and third copy are only built while at least half of the device memory stays free, so `brick_copies` may be
+ * The bricked layout keeps the reference's linear array (feeders, download, building copies) next to the brick copies built so
+ * far; every copy but the first is only built while at least half of the device memory stays free, so `brick_copies` may stay
  * smaller than `brick_copies_wanted` — a speed cliff this call makes visible (axis-aligned views along x / y then read the
- * (x,y) copy).  vr_hip_release_linear_copy frees the linear array once nothing will need it again: afterwards rendering works
- * as before, while vr_hip_volume_minmax / _histogram / vr_hip_download_volume / vr_hip_set_layout return VR_ERR_NOT_READY
- * until the next set_volume.  Refused (VR_ERR_INVALID) when the linear array is the only copy a render path can read. */
+ * (x,y) copy).  vr_hip_release_linear_copy frees the linear array once nothing will need it again: afterwards frames read the
+ * copies that are resident (no further copy can be built: prepare first), while vr_hip_volume_minmax / _histogram /
+ * vr_hip_download_volume / vr_hip_set_layout / vr_hip_prepare return VR_ERR_NOT_READY until the next set_volume, and so does a
+ * frame that no resident copy can serve.  Refused (VR_ERR_INVALID) when no brick copy is resident yet, for edges above 2048,
+ * and while the index-arithmetic path is forced (vr_hip_set_wide_addressing 1). */
 typedef struct vr_volume_info {
 	uint32_t dim_x, dim_y, dim_z, bytes_per_voxel;
 	uint32_t layout;                /* vr_layout actually in use */
@@ -226,6 +250,11 @@ typedef struct vr_volume_info {
 	uint32_t run_copy;              /* further copies resident: bit 0 run bricks along z, bit 1 run bricks along y (one 8-byte gather per
 	                                   TRILINEAR sample), bit 2 voxel bricks (one voxel per element, what NEAREST reads) */
 	uint64_t linear_bytes, bricked_bytes;
+	uint32_t copies;                /* VR_COPY_* bits of the copies resident now */
+	uint32_t copies_in_policy;      /* VR_COPY_* bits the layout policy has at this volume size (what frames may still build) */
+	uint32_t copies_refused;        /* VR_COPY_* bits whose build was refused (HBM guard / allocation); not retried until vr_hip_prepare or set_volume */
+	float    build_ms[VR_COPY_KINDS]; /* hipEvent time of the kernel that built copy i (0 if never built) */
+	float    upload_ms;             /* wall time of the upload / generation of the linear array in the last set_volume */
 } vr_volume_info;
 int vr_hip_volume_info(vr_ctx *ctx, vr_volume_info *out);
 int vr_hip_release_linear_copy(vr_ctx *ctx);

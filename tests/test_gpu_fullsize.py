@@ -74,6 +74,41 @@ def test_whole_frames_equal_the_reference_renderer_c4(vr, gpu, c4):
     scene.set_modes(esl=True, ray_threshold=0.95)
 
 
+def _restatement_hash_cases(config):
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_fullsize_trilinear.json")) as f:
+        return [c for c in json.load(f)["cases"] if c["config"] == config]
+
+
+def _check_trilinear_whole_frames(vr, gpu, scene, cases, width, height):
+    """TRILINEAR / TRILINEAR_Q8 whole frames under the AUTOMATIC per-view policy (brick copy, tile phase, lane order as
+    vr_hip_api.cpp picks them) == the frames of the CPU restatement (oracle/gen_golden_fullsize_trilinear.py): FNV-1a32 and
+    covered-pixel count.  Pins HIP == restatement, not HIP == GPURenderer4 (which cannot run here): parity of the trilinear
+    sampler against the reference stays unpinned, DESIGN.md section 1."""
+    assert len(cases) == 32
+    samp = {"trilinear": vr.SAMPLE_TRILINEAR, "trilinear_q8": vr.SAMPLE_TRILINEAR_Q8}
+    gpu.set_brick_plane(-1)
+    gpu.set_tile_mapping(-1, 0, 0)
+    bad = []
+    for case in cases:
+        scene.set_modes(esl=(case["mode"] == "default"), ray_threshold=(0.95 if case["mode"] == "default" else 1.0))
+        assert np.float32(scene.params.ray_step) == np.float32(case["ray_step"])
+        out = gpu.render_volume(scene.frame_params(vr.benchmark_view(width, height, case["view"]), samp[case["sampling"]]))
+        if fnv1a32(out) != case["fnv"] or int((out[..., 3] != 0).sum()) != case["nonzero_alpha"]:
+            bad.append((case["sampling"], case["mode"], case["view"], fnv1a32(out), case["fnv"]))
+    scene.set_modes(esl=True, ray_threshold=0.95)
+    assert not bad, bad
+
+
+def test_trilinear_whole_frames_equal_the_restatement_c4(vr, gpu, c4):
+    """8 views x {default, no optims} x {TRILINEAR, Q8} at 1024^3 @ 2048^2: every view's chosen copy (quad XY / XZ / YZ: exactly
+    2^32 bytes behind 32-bit offsets; run bricks along z / y: 64-bit table addresses), phase and lane order over the WHOLE frame."""
+    scene, _ = c4
+    _check_trilinear_whole_frames(vr, gpu, scene, _restatement_hash_cases("c4"), W, W)
+    info = gpu.volume_info()                                        # the copies the per-view policy chose from were all built (first use)
+    assert info.brick_copies == 3 and (info.run_copy & 3) == 3 and info.copies_refused == 0
+
+
 def test_partition_concat_equals_whole_frame(vr, gpu, c4):
     import torch
     dmod = importlib.import_module("volume-rendering_amd.distributed")
@@ -143,6 +178,8 @@ def test_config3_512_at_1080p(vr, gpu, oracle):
         out = gpu.render_volume(scene.frame_params(vr.benchmark_view(1920, 1080, case["view"]), vr.SAMPLE_NEAREST))
         assert fnv1a32(out) == case["fnv"], (case["view"], case["mode"])
         assert int((out[..., 3] != 0).sum()) == case["nonzero_alpha"]
+    # whole TRILINEAR / Q8 frames against the CPU restatement (non-square viewport, 1080 rows = 67.5 tile rows)
+    _check_trilinear_whole_frames(vr, gpu, scene, _restatement_hash_cases("c3"), 1920, 1080)
     # ESL never changes the NEAREST image; ERT changes it only by what is cut after alpha > 0.95
     view = vr.benchmark_view(1920, 1080, 0)
     scene.set_modes(esl=True, ray_threshold=0.95)

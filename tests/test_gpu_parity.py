@@ -328,8 +328,9 @@ def test_multi_device_frame_equals_single_device(vr, gpu, golden):
 
 
 def test_volume_info_and_release_of_the_linear_copy(vr, golden):
-    """vr_hip_volume_info reports the copies that were actually built; after vr_hip_release_linear_copy rendering is unchanged
-    and everything that needs the linear array says so instead of reading freed memory."""
+    """Brick copies are built on first use (or by vr_hip_prepare) and vr_hip_volume_info reports them; after
+    vr_hip_release_linear_copy rendering is unchanged and everything that needs the linear array says so instead of reading
+    freed memory — including a frame that no resident copy can serve (NEAREST on the index-arithmetic path)."""
     r = vr.HipRenderer(0)
     try:
         st = golden.volume_state("bucky")
@@ -338,22 +339,70 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         r.set_window_buffer(256, 256)
         info = r.volume_info()
         assert (info.dim_x, info.dim_y, info.dim_z, info.bytes_per_voxel) == (32, 32, 32, 1)
-        assert info.layout == vr.LAYOUT_BRICKED and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7
-        assert info.linear_resident == 1 and info.linear_bytes >= 32 ** 3 and info.run_copy == 7 and info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3
+        # nothing but the linear array after set_volume; the policy has all six copies at this size
+        assert info.layout == vr.LAYOUT_BRICKED and info.copies == 0 and info.bricked_bytes == 0 and info.copies_in_policy == vr.COPY_ALL
+        assert info.brick_copies == 0 and info.brick_copies_wanted == 3 and info.linear_resident == 1 and info.linear_bytes >= 32 ** 3
+        with pytest.raises(vr.VrError) as e:
+            r.release_linear_copy()                                            # no brick copy resident yet
+        assert e.value.code == 1
         case = [c for c in golden.cases(True) if c["label"] == "bench256_view1_default"][0]
-        before = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
+        # a NEAREST frame builds the voxel bricks and nothing else (a NEAREST-only session)
+        near = r.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
+        info = r.volume_info()
+        assert info.copies == vr.COPY_VOXEL and info.run_copy == 4 and info.bricked_bytes == 32 ** 3 and info.build_ms[5] > 0
+        # view 1 is oblique: a TRILINEAR frame builds one run copy, not the quad planes
+        tri = r.render_volume(golden.params(case, vr.SAMPLE_TRILINEAR))
+        info = r.volume_info()
+        assert info.copies in (vr.COPY_VOXEL | vr.COPY_RUN_Z, vr.COPY_VOXEL | vr.COPY_RUN_Y) and info.brick_copies == 0
+        r.prepare()                                                            # everything the policy has
+        info = r.volume_info()
+        assert info.copies == vr.COPY_ALL and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7 and info.run_copy == 7
+        assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3
+        assert all(ms > 0 for ms in info.build_ms) and info.copies_refused == 0 and info.upload_ms > 0
+        before = [near, tri]
         r.release_linear_copy()
         info = r.volume_info()
         assert info.linear_resident == 0 and info.linear_bytes == 0 and info.brick_copies == 3
         after = [r.render_volume(golden.params(case, m)) for m in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
         assert all(np.array_equal(a, b) for a, b in zip(before, after))
         assert np.array_equal(after[0], golden.frame(case))
-        for call in (r.volume_minmax, r.volume_histogram, r.download_volume, lambda: r.set_layout(vr.LAYOUT_LINEAR)):
+        for call in (r.volume_minmax, r.volume_histogram, r.download_volume, lambda: r.set_layout(vr.LAYOUT_LINEAR),
+                     lambda: r.set_wide_addressing(1)):
             with pytest.raises(vr.VrError) as e:
                 call()
             assert e.value.code == 5 and "released" in str(e.value)            # VR_ERR_NOT_READY
+        r.set_wide_addressing(2)                                               # the 64-bit TABLE path reads brick copies: still fine
+        assert np.array_equal(r.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), near)
+        r.set_wide_addressing(0)
+        # a context that released the linear array after preparing ONLY the TRILINEAR copies: NEAREST falls back to the quad copy
+        r.set_volume(golden.voxels("bucky"))
+        r.prepare(vr.COPY_QUAD_XY | vr.COPY_RUN_Z)
+        r.release_linear_copy()
+        assert np.array_equal(r.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), near)
+        assert np.array_equal(r.render_volume(golden.params(case, vr.SAMPLE_TRILINEAR)), tri)
+        assert r.volume_info().copies == vr.COPY_QUAD_XY | vr.COPY_RUN_Z
+        with pytest.raises(vr.VrError) as e:
+            r.prepare(vr.COPY_VOXEL)
+        assert e.value.code == 5
+        # ... and one that holds only the voxel bricks cannot serve TRILINEAR: refused, not a NULL volume pointer in a kernel
+        r.set_volume(golden.voxels("bucky"))
+        r.prepare(vr.COPY_VOXEL)
+        r.release_linear_copy()
+        assert np.array_equal(r.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), near)
+        with pytest.raises(vr.VrError) as e:
+            r.render_volume(golden.params(case, vr.SAMPLE_TRILINEAR))
+        assert e.value.code == 5 and "released" in str(e.value)
+        with pytest.raises(vr.VrError) as e:
+            r.set_wide_addressing(1)
+        assert e.value.code == 5
         r.set_volume(golden.voxels("bucky"))                                   # a new volume brings everything back
         assert r.volume_info().linear_resident == 1 and r.volume_minmax()[1] == 8
+        r.set_wide_addressing(1)
+        r.prepare(vr.COPY_VOXEL)
+        with pytest.raises(vr.VrError) as e:
+            r.release_linear_copy()                                            # the forced index-arithmetic path reads the linear array
+        assert e.value.code == 1
+        r.set_wide_addressing(0)
         r.set_layout(vr.LAYOUT_LINEAR)
         with pytest.raises(vr.VrError) as e:
             r.release_linear_copy()                                            # the linear array is the only copy now

@@ -7,6 +7,9 @@ SAMPLE_TRILINEAR = 1    # vr_sampling.VR_SAMPLE_TRILINEAR — GPURenderer4 seman
 SAMPLE_TRILINEAR_Q8 = 2  # vr_sampling.VR_SAMPLE_TRILINEAR_Q8 — the same with 8-bit filter weights (the texture unit's definition)
 LAYOUT_LINEAR = 0        # vr_layout
 LAYOUT_BRICKED = 1
+# VR_COPY_* bits (vr_hip_prepare / vr_volume_info.copies): quad bricks per chunk plane, run bricks along z / y, voxel bricks
+COPY_QUAD_XY, COPY_QUAD_XZ, COPY_QUAD_YZ, COPY_RUN_Z, COPY_RUN_Y, COPY_VOXEL, COPY_ALL = 1, 2, 4, 8, 16, 32, 63
+COPY_NAMES = ("quad_xy", "quad_xz", "quad_yz", "run_z", "run_y", "voxel")
 TF_SIZE = 128
 ESL_VOLUME_SIZE = 1024
 
@@ -45,7 +48,9 @@ class VrParams(C.Structure):
 class VrVolumeInfo(C.Structure):
     _fields_ = [("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("dim_z", C.c_uint32), ("bytes_per_voxel", C.c_uint32),
                 ("layout", C.c_uint32), ("brick_copies", C.c_uint32), ("brick_copies_wanted", C.c_uint32), ("brick_planes", C.c_uint32),
-                ("linear_resident", C.c_uint32), ("run_copy", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64)]
+                ("linear_resident", C.c_uint32), ("run_copy", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64),
+                ("copies", C.c_uint32), ("copies_in_policy", C.c_uint32), ("copies_refused", C.c_uint32),
+                ("build_ms", C.c_float * 6), ("upload_ms", C.c_float)]
 
 
 class VrTiming(C.Structure):
@@ -101,6 +106,7 @@ def lib():
         "vr_hip_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, P(u32), P(u64)]),
         "vr_hip_volume_info": (C.c_int, [vp, P(VrVolumeInfo)]),
         "vr_hip_release_linear_copy": (C.c_int, [vp]),
+        "vr_hip_prepare": (C.c_int, [vp, u32]),
         "vr_hip_multi_create": (C.c_int, [C.c_int, P(C.c_int), P(vp)]),
         "vr_hip_multi_destroy": (None, [vp]),
         "vr_hip_multi_last_error": (C.c_char_p, [vp]),

@@ -105,6 +105,9 @@ constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 //    lowest, y in the middle and x in the top slot — measured 10 % faster than the order above on 1024^3 u16.
 // All measured against the alternatives with scripts/gpu_variants.sh / gpu_planes.sh.
 enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
+// the brick copies a context may hold (bit i of vr_hip_prepare's mask / vr_volume_info::copies = copy i): quad bricks per chunk
+// plane, run bricks along z / y, voxel bricks
+enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyKinds = 6 };
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
 	constexpr uint8_t table[4][9] = {
@@ -148,6 +151,8 @@ inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bytes_per_voxel,
                            const float *tf_premult /* 128 x float4 */, const uint32_t *esl_bits /* 1024 */,
                            void *out_rgba, hipStream_t stream);
+
+bool raymarch_reads_linear(const RayKernelArgs &a, bool have_bricked, uint32_t bytes_per_voxel);
 
 hipError_t launch_minmax(const void *volume, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                          uint32_t esl_block_dims, uint8_t *minmax_dev /* 32768 x {min,max} */, hipStream_t stream);

@@ -39,11 +39,15 @@ struct vr_ctx {
 	float tf_zero_below = -1.0f;            // leading all-zero entries of the resident TF (exact transparent-sample shortcut)
 	// volume
 	void *vol = nullptr; uint64_t vol_elems = 0; uint32_t dim[3] = { 0, 0, 0 }; uint32_t bpv = 0;
-	void *vol_bricked = nullptr;            // brick copy with chunk plane (x,y) (vr_device.h), built by set_volume
-	void *vol_plane[kPlanes] = { nullptr, nullptr, nullptr };   // [0] = vol_bricked; [1], [2]: chunk planes (x,z), (y,z) — u8, edges <= 1024
-	void *vol_run = nullptr;                // run bricks (vr_device.h kLayoutRun, runs along z): one 8-byte gather per sample
-	void *vol_run_y = nullptr;              // run bricks with the runs along y (kLayoutRunY): for views that march mostly along z
-	void *vol_near = nullptr;               // voxel bricks (kLayoutVoxel): one voxel per element, what NEAREST sampling reads
+	// Brick copies of the resident volume (vr_device.h), built ON FIRST USE by the frame that wants them (or ahead of time by
+	// vr_hip_prepare): a NEAREST-only session never pays for the quad / run copies, a session that only looks along z never
+	// builds the (x,z) / (y,z) planes.  copy[kCopyQuadXY..YZ] = quad bricks per chunk plane, kCopyRunZ / kCopyRunY = run bricks,
+	// kCopyVoxel = voxel bricks (what NEAREST reads).  copy_failed: a build was refused (HBM guard / allocation) — not retried
+	// until the next set_volume, so a frame never stalls twice on the same refusal.
+	void *copy[kCopyKinds] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	float copy_build_ms[kCopyKinds] = { 0, 0, 0, 0, 0, 0 };
+	bool copy_failed[kCopyKinds] = { false, false, false, false, false, false };
+	float upload_ms = 0;                    // host -> HBM copy (or generation) of the linear array in the last set_volume
 	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
 	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
 	uint32_t layout = VR_LAYOUT_BRICKED;
@@ -83,6 +87,9 @@ int fail(vr_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 			return fail((c), e_ == hipErrorOutOfMemory ? VR_ERR_ALLOC : VR_ERR_HIP, #expr, e_);      \
 		}                                                                                            \
 	} while (0)
+
+bool copy_possible(const vr_ctx *c, uint32_t kind);
+const void *copy_for(vr_ctx *c, uint32_t kind);
 
 bool finite3(const float *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
 
@@ -276,14 +283,15 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		a.near_scaled = (pow2(c->dim[0]) && pow2(c->dim[1]) && pow2(c->dim[2]) && !(c->force_clamp_fetch & 2u)) ? 1u : 0u;
 	}
 	a.force_wide = c->force_wide;
-	a.layout = c->vol_bricked ? kLayoutBricked : kLayoutLinear;
-	const void *brick_copy = nullptr;
+	const bool bricked = c->layout == VR_LAYOUT_BRICKED;
+	a.layout = bricked ? kLayoutBricked : kLayoutLinear;
 	bool run_candidate = false, run_if_unaligned = false;
 	uint32_t run_layout = kLayoutRun;        // which run copy a run-brick frame reads: runs along z unless the view marches along z
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
+	// Copies are built on first use (copy_for): `have` asks without building.
 	a.brick_plane = kPlaneXY;
-	if (p->sampling != VR_SAMPLE_NEAREST && a.layout == kLayoutBricked && !c->force_wide) {
+	if (p->sampling != VR_SAMPLE_NEAREST && bricked && !c->force_wide) {
 		uint32_t plane = kPlaneXY;
 		if (c->brick_plane_force >= 0) plane = (uint32_t) c->brick_plane_force;
 		else {
@@ -292,26 +300,26 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			const float dx = std::fabs(p->view.direction[0] * a.half_x), dy = std::fabs(p->view.direction[1] * a.half_y),
 			            dz = std::fabs(p->view.direction[2] * a.half_z);
 			const float dmax = std::fmax(dx, std::fmax(dy, dz));
-			if (dz >= dx && dz >= dy && c->vol_run_y) run_layout = kLayoutRunY;     // runs across the march, never along it
+			if (dz >= dx && dz >= dy && copy_possible(c, kCopyRunY)) run_layout = kLayoutRunY;     // runs across the march, never along it
 			if (dmax > 0.98f * std::sqrt(dx * dx + dy * dy + dz * dz)) {
 				plane = dz >= dx && dz >= dy ? kPlaneXY : (dy >= dx ? kPlaneXZ : kPlaneYZ);
 				// Perspective along x or y: the pixel pitch grows from 0.4 to 1.1 cells along the march, most lane quads straddle
 				// chunks, and the run bricks — whose runs (along z) then lie across the march — are faster (measured 2.08 / 2.18 ms
 				// against 2.49 / 2.51 ms on the benchmark poses).  Along z the runs lie along the march and the quad copy wins
 				// (2.48 against 2.99 ms).  Orthogonal views along an axis are decided below, from how well their quads can be aligned.
-				if (p->view.perspective && (plane != kPlaneXY || c->vol_run_y)) run_candidate = true;
+				if (p->view.perspective && (plane != kPlaneXY || run_layout == kLayoutRunY)) run_candidate = true;
 				else if (!p->view.perspective) run_if_unaligned = true;
 			} else {
 				run_candidate = true;       // not along an axis: lane quads straddle chunks whatever the plane -> one 8-byte gather
 			}
 		}
-		if (plane < kPlanes && c->vol_plane[plane]) a.brick_plane = plane;
-		else if (plane == kPlanes && c->vol_run) a.layout = kLayoutRun;               // forced: 3 = runs along z, 4 = runs along y
-		else if (plane == kPlanes + 1 && c->vol_run_y) a.layout = kLayoutRunY;
-		if (run_candidate && c->vol_run) a.layout = run_layout;
+		if (plane < kPlanes && copy_possible(c, kCopyQuadXY + plane)) a.brick_plane = plane;
+		else if (plane == kPlanes && copy_possible(c, kCopyRunZ)) a.layout = kLayoutRun;               // forced: 3 = runs along z, 4 = runs along y
+		else if (plane == kPlanes + 1 && copy_possible(c, kCopyRunY)) a.layout = kLayoutRunY;
+		if (run_candidate && copy_possible(c, run_layout == kLayoutRunY ? kCopyRunY : kCopyRunZ)) a.layout = run_layout;
 	}
 	// NEAREST: the voxel bricks (one voxel per element) unless a quad copy is forced (testing) or a 64-bit path is
-	if (p->sampling == VR_SAMPLE_NEAREST && a.layout == kLayoutBricked && c->vol_near && c->brick_plane_force < 0 && c->force_wide != 1)
+	if (p->sampling == VR_SAMPLE_NEAREST && bricked && copy_possible(c, kCopyVoxel) && c->brick_plane_force < 0 && c->force_wide != 1)
 		a.layout = kLayoutVoxel;
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
@@ -339,12 +347,29 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		// An orthogonal view along an axis whose pixels sit exactly on cell boundaries can carry rounding noise in its direction
 		// (pose (180,90,0): components of 4e-8) that moves boundary pixels to the other neighbour part-way along the ray and
 		// differently across the frame: no phase aligns it.  Measured on that pose: 3.18 ms with the run bricks against 3.71 ms.
-		if (run_if_unaligned && c->vol_run && hit->straddle_permille > 150u) a.layout = run_layout;
+		if (run_if_unaligned && hit->straddle_permille > 150u && copy_possible(c, run_layout == kLayoutRunY ? kCopyRunY : kCopyRunZ)) a.layout = run_layout;
 	}
-	if (a.layout == kLayoutRun) brick_copy = c->vol_run;
-	else if (a.layout == kLayoutRunY) brick_copy = c->vol_run_y;
-	else if (a.layout == kLayoutVoxel) brick_copy = c->vol_near;
-	else if (a.layout == kLayoutBricked) brick_copy = c->vol_plane[a.brick_plane];
+	// The copy this frame reads, built now if this is its first use.  A build that is refused (HBM guard, allocation, linear array
+	// released) degrades to the next best resident copy; the image is the same.
+	const void *brick_copy = nullptr;
+	if (a.layout != kLayoutLinear) {
+		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel : kCopyQuadXY + a.brick_plane;
+		brick_copy = copy_for(c, want);
+		if (brick_copy == nullptr && want != kCopyQuadXY) {
+			a.layout = kLayoutBricked; a.brick_plane = kPlaneXY;
+			c->map_cached = 0; c->map_next = 0;              // lane orders were chosen for the copy that could not be had
+			brick_copy = copy_for(c, kCopyQuadXY);
+		}
+		if (brick_copy == nullptr) {                         // no quad copy either: any resident copy this sampling mode can read
+			if (p->sampling == VR_SAMPLE_NEAREST && c->copy[kCopyVoxel] && c->force_wide != 1) { a.layout = kLayoutVoxel; brick_copy = c->copy[kCopyVoxel]; }
+			else if (p->sampling != VR_SAMPLE_NEAREST && !c->force_wide && c->copy[kCopyRunZ]) { a.layout = kLayoutRun; brick_copy = c->copy[kCopyRunZ]; }
+			else if (p->sampling != VR_SAMPLE_NEAREST && !c->force_wide && c->copy[kCopyRunY]) { a.layout = kLayoutRunY; brick_copy = c->copy[kCopyRunY]; }
+			else a.layout = kLayoutLinear;
+		}
+	}
+	if (raymarch_reads_linear(a, brick_copy != nullptr, c->bpv) && c->vol == nullptr)
+		return fail(c, VR_ERR_NOT_READY, "this frame needs the linear array, which was released (vr_hip_release_linear_copy): no resident brick copy "
+		                                 "serves this sampling mode / addressing path — prepare it before releasing, or set the volume again");
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
@@ -357,75 +382,97 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 }
 
 int ready(vr_ctx *c) {
-	if (c->vol == nullptr && c->vol_bricked == nullptr) return fail(c, VR_ERR_NOT_READY, "render before set_volume");
+	bool any = c->vol != nullptr;
+	for (uint32_t k = 0; k < kCopyKinds; k++) any = any || c->copy[k] != nullptr;
+	if (!any) return fail(c, VR_ERR_NOT_READY, "render before set_volume");
 	if (!c->tf_set) return fail(c, VR_ERR_NOT_READY, "render before set_transfer_fn");
 	return VR_OK;
 }
 
+// Waits for every frame this context has queued (on its own or on callers' streams) and for its own stream: what the reference's
+// synchronous set_* calls imply, without stalling other contexts or streams of the device (no hipDeviceSynchronize).
+hipError_t drain(vr_ctx *c) {
+	for (int i = 0; i < kEventRing; i++)
+		if (c->ring[i].pending) { hipError_t e = hipEventSynchronize(c->ring[i].stop); if (e != hipSuccess) return e; }
+	return hipStreamSynchronize(c->stream);
+}
+
 void free_bricks(vr_ctx *c) {
-	for (uint32_t i = 0; i < kPlanes; i++) if (c->vol_plane[i]) { (void) hipFree(c->vol_plane[i]); c->vol_plane[i] = nullptr; }
-	if (c->vol_run) { (void) hipFree(c->vol_run); c->vol_run = nullptr; }
-	if (c->vol_run_y) { (void) hipFree(c->vol_run_y); c->vol_run_y = nullptr; }
-	if (c->vol_near) { (void) hipFree(c->vol_near); c->vol_near = nullptr; }
-	c->vol_bricked = nullptr;
+	for (uint32_t k = 0; k < kCopyKinds; k++) {
+		if (c->copy[k]) { (void) hipFree(c->copy[k]); c->copy[k] = nullptr; }
+		c->copy_build_ms[k] = 0; c->copy_failed[k] = false;
+	}
+}
+
+uint32_t max_dim_of(const vr_ctx *c) { return std::max(c->dim[0], std::max(c->dim[1], c->dim[2])); }
+
+uint64_t copy_bytes(const vr_ctx *c, uint32_t kind) {
+	if (kind <= kCopyQuadYZ) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
+	if (kind == kCopyVoxel) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
+	return run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
+}
+
+// does the layout policy have this copy at this volume size at all?  (quad (x,y): always; the other planes and the run bricks:
+// 1-byte voxels, edges the 32-bit tables cover; voxel bricks: wherever the address tables reach)
+bool copy_in_policy(const vr_ctx *c, uint32_t kind) {
+	if (c->layout != VR_LAYOUT_BRICKED || c->dim[0] == 0) return false;
+	if (kind == kCopyQuadXY) return true;
+	if (kind == kCopyVoxel) return max_dim_of(c) <= 2048u;
+	if (kind == kCopyQuadXZ || kind == kCopyQuadYZ) return c->bpv == 1 && max_dim_of(c) <= 1024u && copy_bytes(c, kind) <= (1ull << 32);
+	return c->bpv == 1 && max_dim_of(c) <= 1024u;
+}
+
+// resident, or buildable on first use (the policy has it, the linear array is still there, no earlier build was refused)
+bool copy_possible(const vr_ctx *c, uint32_t kind) {
+	if (c->copy[kind]) return true;
+	return copy_in_policy(c, kind) && c->vol != nullptr && !c->copy_failed[kind];
+}
+
+// Builds copy `kind` from the linear array on the context's stream and waits for it (a one-time stall of the first frame that
+// wants it: 6-8 ms per copy at 1024^3).  Every copy but the first quad copy is only built while half of the HBM stays free.
+int build_copy(vr_ctx *c, uint32_t kind) {
+	if (c->copy[kind]) return VR_OK;
+	if (!copy_possible(c, kind)) return VR_ERR_NOT_READY;
+	const uint64_t bytes = copy_bytes(c, kind);
+	if (kind != kCopyQuadXY) {
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) { (void) hipGetLastError(); c->copy_failed[kind] = true; return VR_ERR_ALLOC; }
+	}
+	void *dst = nullptr;
+	if (hipMalloc(&dst, bytes) != hipSuccess) { (void) hipGetLastError(); c->copy_failed[kind] = true; return fail(c, VR_ERR_ALLOC, "brick copy allocation failed"); }
+	hipError_t e = hipEventRecord(c->aux_start, c->stream);
+	if (e == hipSuccess) {
+		if (kind <= kCopyQuadYZ) e = launch_brickify(c->vol, dst, c->bpv, kind - kCopyQuadXY, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else if (kind == kCopyVoxel) e = launch_brickify_voxel(c->vol, dst, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else e = launch_brickify_run(c->vol, dst, kind == kCopyRunY ? kLayoutRunY : kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream);
+	}
+	if (e == hipSuccess) e = hipEventRecord(c->aux_stop, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) { (void) hipGetLastError(); (void) hipFree(dst); c->copy_failed[kind] = true; return fail(c, VR_ERR_HIP, "brick copy build failed", e); }
+	(void) hipEventElapsedTime(&c->copy_build_ms[kind], c->aux_start, c->aux_stop);
+	c->copy[kind] = dst;
+	return VR_OK;
+}
+
+const void *copy_for(vr_ctx *c, uint32_t kind) {
+	if (c->copy[kind] == nullptr) (void) build_copy(c, kind);
+	return c->copy[kind];
 }
 
 int alloc_volume(vr_ctx *c, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
 	if (x == 0 || y == 0 || z == 0 || x > 65535u || y > 65535u || z > 65535u)       // Model::dims is ushort3
 		return fail(c, VR_ERR_INVALID, "volume dims out of range (1..65535)");
 	if (bpv != 1 && bpv != 2) return fail(c, VR_ERR_INVALID, "bytes_per_voxel must be 1 or 2");
+	VR_TRY(c, drain(c));                         // frames still reading the volume we are about to free
 	if (c->vol) { (void) hipFree(c->vol); c->vol = nullptr; }
 	free_bricks(c);
+	c->map_cached = 0; c->map_next = 0;          // cached tile mappings belong to the previous volume
 	c->dim[0] = c->dim[1] = c->dim[2] = 0;
 	const uint64_t elems = (uint64_t) x * y * z;
 	const uint64_t slack = volume_tail_slack(x, y);
 	VR_TRY(c, hipMalloc(&c->vol, (elems + slack) * bpv));
 	VR_TRY(c, hipMemsetAsync((uint8_t *) c->vol + elems * bpv, 0, slack * bpv, c->stream));
 	c->vol_elems = elems; c->dim[0] = x; c->dim[1] = y; c->dim[2] = z; c->bpv = bpv;
-	return VR_OK;
-}
-
-// builds (or drops) the bricked TRILINEAR copy of the resident linear volume according to c->layout
-int finalize_volume(vr_ctx *c) {
-	free_bricks(c);
-	c->map_cached = 0; c->map_next = 0;          // cached tile mappings belong to the previous set of copies
-	if (c->vol == nullptr || c->layout != VR_LAYOUT_BRICKED)
-		return VR_OK;
-	const uint64_t bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
-	VR_TRY(c, hipMalloc(&c->vol_plane[kPlaneXY], bytes));
-	c->vol_bricked = c->vol_plane[kPlaneXY];
-	VR_TRY(c, launch_brickify(c->vol, c->vol_bricked, c->bpv, kPlaneXY, c->dim[0], c->dim[1], c->dim[2], c->stream));
-	// the two other chunk planes: 1-byte voxels, edges the 32-bit tables cover, and only while half of the HBM stays free
-	const uint32_t max_dim = std::max(c->dim[0], std::max(c->dim[1], c->dim[2]));
-	for (uint32_t plane = kPlaneXZ; plane < kPlanes && c->bpv == 1 && max_dim <= 1024u && bytes <= (1ull << 32); plane++) {
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) break;
-		if (hipMalloc(&c->vol_plane[plane], bytes) != hipSuccess) { c->vol_plane[plane] = nullptr; (void) hipGetLastError(); break; }
-		VR_TRY(c, launch_brickify(c->vol, c->vol_plane[plane], c->bpv, plane, c->dim[0], c->dim[1], c->dim[2], c->stream));
-	}
-	// the voxel bricks NEAREST sampling reads (a quarter of a quad copy): wherever the address tables reach
-	if (max_dim <= 2048u) {
-		const uint64_t near_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && near_bytes < free_b && free_b - near_bytes >= total_b / 2) {
-			if (hipMalloc(&c->vol_near, near_bytes) != hipSuccess) { c->vol_near = nullptr; (void) hipGetLastError(); }
-			else VR_TRY(c, launch_brickify_voxel(c->vol, c->vol_near, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream));
-		}
-	}
-	// the run bricks for views that are not along an axis: same conditions (1-byte voxels, table-addressable edges, spare HBM)
-	if (c->bpv == 1 && max_dim <= 1024u) {
-		const uint64_t run_bytes = run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && run_bytes < free_b && free_b - run_bytes >= total_b / 2) {
-			if (hipMalloc(&c->vol_run, run_bytes) != hipSuccess) { c->vol_run = nullptr; (void) hipGetLastError(); }
-			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run, kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream));
-		}
-		if (c->vol_run && hipMemGetInfo(&free_b, &total_b) == hipSuccess && run_bytes < free_b && free_b - run_bytes >= total_b / 2) {
-			if (hipMalloc(&c->vol_run_y, run_bytes) != hipSuccess) { c->vol_run_y = nullptr; (void) hipGetLastError(); }
-			else VR_TRY(c, launch_brickify_run(c->vol, c->vol_run_y, kLayoutRunY, c->dim[0], c->dim[1], c->dim[2], c->stream));
-		}
-	}
-	VR_TRY(c, hipStreamSynchronize(c->stream));
 	return VR_OK;
 }
 
@@ -503,9 +550,11 @@ int vr_hip_set_transfer_fn(vr_ctx *c, const float *tf, const uint32_t *esl) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (tf == nullptr || esl == nullptr) return fail(c, VR_ERR_INVALID, "transfer_fn / esl_volume is NULL");
 	VR_TRY(c, hipSetDevice(c->device));
-	// Frames queued by vr_hip_render_device run asynchronously (context stream or a caller's stream): wait for them before the
-	// tables they read are rewritten, then upload on the context stream and wait again — the reference is synchronous here too.
-	VR_TRY(c, hipDeviceSynchronize());
+	// Frames queued by vr_hip_render_device run asynchronously (context stream or a caller's stream): wait for THIS CONTEXT'S
+	// frames (the event ring records every one of them) before the tables they read are rewritten, then upload on the context
+	// stream and wait again — the reference is synchronous here too, and calls this on every mouse-motion event of its TF editor
+	// (UI.cpp:52-61,317-341), so other contexts and streams of the device are not stalled (no hipDeviceSynchronize).
+	VR_TRY(c, drain(c));
 	VR_TRY(c, hipMemcpyAsync(c->tf, tf, VR_TF_SIZE * 4 * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	VR_TRY(c, hipMemcpyAsync(c->esl, esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
@@ -524,9 +573,11 @@ int vr_hip_set_volume(vr_ctx *c, const void *host, uint32_t x, uint32_t y, uint3
 	VR_TRY(c, hipSetDevice(c->device));
 	int rc = alloc_volume(c, x, y, z, bpv);
 	if (rc) return rc;
+	const auto t0 = std::chrono::steady_clock::now();
 	VR_TRY(c, hipMemcpy(c->vol, host, c->vol_elems * bpv, hipMemcpyHostToDevice));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return finalize_volume(c);
+	c->upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return VR_OK;                                // brick copies are built by the first frame that reads them (or vr_hip_prepare)
 }
 
 int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y, uint32_t z, uint32_t bpv) {
@@ -537,24 +588,32 @@ int vr_hip_set_volume_device(vr_ctx *c, const void *dev, uint32_t x, uint32_t y,
 	if (rc) return rc;
 	// on the context's own (non-blocking) stream: a device-to-device hipMemcpy on the null stream may return before it has
 	// finished and would not be ordered before the brick builder below
+	const auto t0 = std::chrono::steady_clock::now();
 	VR_TRY(c, hipMemcpyAsync(c->vol, dev, c->vol_elems * bpv, hipMemcpyDeviceToDevice, c->stream));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return finalize_volume(c);
+	c->upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return VR_OK;
 }
 
 int vr_hip_set_layout(vr_ctx *c, uint32_t layout) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (layout != VR_LAYOUT_LINEAR && layout != VR_LAYOUT_BRICKED) return fail(c, VR_ERR_INVALID, "unknown volume layout");
 	VR_TRY(c, hipSetDevice(c->device));
-	VR_TRY(c, hipDeviceSynchronize());           // a frame may still be reading the copy we are about to drop
+	VR_TRY(c, drain(c));                         // a frame may still be reading the copies we are about to drop
 	if (c->vol == nullptr && c->dim[0] != 0)
 		return fail(c, VR_ERR_NOT_READY, "the linear copy was released (vr_hip_release_linear_copy): the brick copies cannot be rebuilt or dropped");
 	c->layout = layout;
-	return finalize_volume(c);
+	free_bricks(c);
+	c->map_cached = 0; c->map_next = 0;
+	return VR_OK;
 }
 
 int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 	if (c == nullptr) return VR_ERR_INVALID;
+	// The index-arithmetic path (1) reads the linear array for NEAREST: refused once that array was released (the frame
+	// would otherwise be launched with a NULL volume pointer).  launch_frame checks the same for every frame.
+	if ((force & 3u) == 1u && c->vol == nullptr && c->dim[0] != 0)
+		return fail(c, VR_ERR_NOT_READY, "the linear copy was released (vr_hip_release_linear_copy): the index-arithmetic path needs it");
 	c->force_wide = force & 3u;                  // 0 auto, 1 arithmetic 64-bit path, 2 table path with 64-bit z offsets
 	c->force_clamp_fetch = (force >> 2) & 3u;    // + 4: clamp the fetch coordinates of every sample (far-away views do that);
 	                                             // + 8: NEAREST never marches in the scaled domain (volumes with power-of-two edges do)
@@ -674,9 +733,11 @@ int vr_hip_generate_volume(vr_ctx *c, uint32_t kind, uint32_t n, uint32_t seed, 
 	VR_TRY(c, hipSetDevice(c->device));
 	int rc = alloc_volume(c, n, n, n, bpv);
 	if (rc) return rc;
+	const auto t0 = std::chrono::steady_clock::now();
 	VR_TRY(c, launch_generate(c->vol, kind, n, seed, bpv, c->stream));
 	VR_TRY(c, hipStreamSynchronize(c->stream));
-	return finalize_volume(c);
+	c->upload_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	return VR_OK;
 }
 
 int vr_hip_download_volume(vr_ctx *c, void *host_out, uint64_t bytes) {
@@ -694,28 +755,56 @@ int vr_hip_volume_info(vr_ctx *c, vr_volume_info *out) {
 	memset(out, 0, sizeof *out);
 	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "volume_info before set_volume");
 	out->dim_x = c->dim[0]; out->dim_y = c->dim[1]; out->dim_z = c->dim[2]; out->bytes_per_voxel = c->bpv;
-	out->layout = c->vol_bricked ? VR_LAYOUT_BRICKED : VR_LAYOUT_LINEAR;
+	out->layout = c->layout;
 	out->linear_resident = c->vol != nullptr ? 1u : 0u;
 	out->linear_bytes = c->vol != nullptr ? (c->vol_elems + volume_tail_slack(c->dim[0], c->dim[1])) * c->bpv : 0;
-	const uint64_t copy_bytes = bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
-	for (uint32_t i = 0; i < kPlanes; i++)
-		if (c->vol_plane[i]) { out->brick_planes |= 1u << i; out->brick_copies++; out->bricked_bytes += copy_bytes; }
-	if (c->vol_run) { out->run_copy |= 1u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
-	if (c->vol_run_y) { out->run_copy |= 2u; out->bricked_bytes += run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]); }
-	if (c->vol_near) { out->run_copy |= 4u; out->bricked_bytes += bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv; }
-	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? ((c->bpv == 1 && std::max(c->dim[0], std::max(c->dim[1], c->dim[2])) <= 1024u && copy_bytes <= (1ull << 32)) ? 3u : 1u) : 0u;
+	for (uint32_t k = 0; k < kCopyKinds; k++) {
+		out->build_ms[k] = c->copy_build_ms[k];
+		if (copy_in_policy(c, k)) out->copies_in_policy |= 1u << k;
+		if (c->copy_failed[k]) out->copies_refused |= 1u << k;
+		if (c->copy[k] == nullptr) continue;
+		out->copies |= 1u << k;
+		out->bricked_bytes += copy_bytes(c, k);
+		if (k <= kCopyQuadYZ) { out->brick_planes |= 1u << k; out->brick_copies++; }
+	}
+	if (c->copy[kCopyRunZ]) out->run_copy |= 1u;
+	if (c->copy[kCopyRunY]) out->run_copy |= 2u;
+	if (c->copy[kCopyVoxel]) out->run_copy |= 4u;
+	out->brick_copies_wanted = (c->layout == VR_LAYOUT_BRICKED) ? (copy_in_policy(c, kCopyQuadXZ) ? 3u : 1u) : 0u;
+	out->upload_ms = c->upload_ms;
 	return VR_OK;
+}
+
+int vr_hip_prepare(vr_ctx *c, uint32_t copies) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "prepare before set_volume");
+	if (copies & ~((1u << kCopyKinds) - 1u)) return fail(c, VR_ERR_INVALID, "unknown copy bits");
+	VR_TRY(c, hipSetDevice(c->device));
+	int worst = VR_OK;
+	for (uint32_t k = 0; k < kCopyKinds; k++) {
+		if (!((copies >> k) & 1u) || c->copy[k] || !copy_in_policy(c, k)) continue;      // copies the policy does not have at this size are skipped
+		if (c->vol == nullptr) return fail(c, VR_ERR_NOT_READY, "the linear copy was released (vr_hip_release_linear_copy): set the volume again");
+		c->copy_failed[k] = false;                   // an explicit request retries an earlier refusal
+		const int rc = build_copy(c, k);
+		if (rc != VR_OK && worst == VR_OK) { worst = rc; if (c->err.empty() || rc == VR_ERR_ALLOC) fail(c, rc, "a brick copy was not built (less than half of the HBM would stay free, or allocation failed)"); }
+	}
+	if (copies) { c->map_cached = 0; c->map_next = 0; }
+	return worst;
 }
 
 int vr_hip_release_linear_copy(vr_ctx *c) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "release_linear_copy before set_volume");
 	if (c->vol == nullptr) return VR_OK;
-	const uint32_t max_dim = std::max(c->dim[0], std::max(c->dim[1], c->dim[2]));
-	if (c->vol_bricked == nullptr || max_dim > 2048u)
-		return fail(c, VR_ERR_INVALID, "the linear array is the only copy every render path can read (linear layout, or an edge above 2048)");
+	bool any = false;
+	for (uint32_t k = 0; k < kCopyKinds; k++) any = any || c->copy[k] != nullptr;
+	if (!any || max_dim_of(c) > 2048u)
+		return fail(c, VR_ERR_INVALID, "the linear array is the only copy a render path can read (no brick copy resident: render a frame or call "
+		                               "vr_hip_prepare first; linear layout; or an edge above 2048)");
+	if (c->force_wide == 1u)
+		return fail(c, VR_ERR_INVALID, "the index-arithmetic path (vr_hip_set_wide_addressing 1) reads the linear array");
 	VR_TRY(c, hipSetDevice(c->device));
-	VR_TRY(c, hipDeviceSynchronize());
+	VR_TRY(c, drain(c));
 	(void) hipFree(c->vol);
 	c->vol = nullptr;
 	return VR_OK;

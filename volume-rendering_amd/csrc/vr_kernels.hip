@@ -5,10 +5,12 @@
 // diffuse shading, front-to-back compositing with a wavefront-ballot early-ray-termination test, RGBA8 store.
 // What it computes is the reference's render_ray (CPURenderer.cpp:11-41 for NEAREST, GPURenderer4.cu:53-87 for
 // TRILINEAR); how it is laid out is not:
-//   * one 64-lane wavefront owns one 8x8-pixel screen tile, a 256-thread workgroup owns a 16x16 tile;
-//   * the transfer function (+ per-entry deltas for the filtered lookup) and the ESL bit-volume live in LDS;
-//   * the loop runs while __ballot(alive) != 0 — a scalar branch on the wave's 64-bit exec summary;
-//   * workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous band of screen tiles;
+//   * one 64-lane wavefront owns one 8x8-pixel screen tile; a workgroup is 8 waves = 32x16 pixels (16 waves = 32x32 for the
+//     64-bit address tables) and stages one copy of the tables per workgroup;
+//   * the transfer function (+ per-entry deltas for the filtered lookup), the ESL bit-volume and per-axis address tables live in LDS;
+//   * liveness is one scalar 64-bit wave mask updated with v_cmp results; the loop runs while it is non-zero (the wave's vote);
+//   * workgroup id = tile number inside 8x8-tile blocks: every block is spread over all eight XCDs (plain interleave — measured
+//     faster than one screen region per XCD, see the tile-map comment in the kernel);
 //   * the frame clear is fused: every pixel of the output is written exactly once (misses write 0), there is no
 //     separate memset pass over the framebuffer (the reference clears first, CPURenderer.cpp:47).
 //
@@ -927,6 +929,19 @@ static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const v
 	if (a.p.sampling == VR_SAMPLE_NEAREST) return launch_sampling<VR_SAMPLE_NEAREST, BPV>(a, linear, bricked, tf, esl, out, stream);
 	if (a.p.sampling == VR_SAMPLE_TRILINEAR_Q8) return launch_sampling<VR_SAMPLE_TRILINEAR_Q8, BPV>(a, linear, bricked, tf, esl, out, stream);
 	return launch_sampling<VR_SAMPLE_TRILINEAR, BPV>(a, linear, bricked, tf, esl, out, stream);
+}
+
+// Will launch_raymarch hand the LINEAR array to the kernel for these arguments?  Mirrors launch_sampling's dispatch: the host uses it
+// to refuse a frame whose variant would read a linear array that was released (vr_hip_release_linear_copy).
+bool raymarch_reads_linear(const RayKernelArgs &a, bool have_bricked, uint32_t bpv) {
+	if (!have_bricked) return true;
+	if (a.layout == kLayoutRun || a.layout == kLayoutRunY) return a.p.sampling == VR_SAMPLE_NEAREST || bpv != 1;
+	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
+	if (a.layout == kLayoutVoxel) return a.p.sampling != VR_SAMPLE_NEAREST;
+	const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * bpv;
+	if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32)) return false;
+	if (a.force_wide != 1 && max_dim <= LutCfg<kAddrLut64>::max_dim) return false;
+	return a.p.sampling == VR_SAMPLE_NEAREST;            // index arithmetic: TRILINEAR has a bricked variant, NEAREST reads the linear array
 }
 
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bpv, const float *tf,

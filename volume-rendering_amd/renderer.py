@@ -137,6 +137,11 @@ class HipRenderer:
         self._check(self._L.vr_hip_volume_info(self._ctx, C.byref(info)), "volume_info")
         return info
 
+    def prepare(self, copies=63):
+        """vr_hip_prepare: build the brick copies named by the VR_COPY_* bits now instead of on first use (default: all the
+        layout policy has at this size).  A refused copy (HBM guard) raises VrError(VR_ERR_ALLOC); frames then read the next best."""
+        self._check(self._L.vr_hip_prepare(self._ctx, int(copies)), "prepare")
+
     def release_linear_copy(self):
         """Frees the linear array (feeders / download / layout changes then need a new set_volume); rendering is unaffected."""
         self._check(self._L.vr_hip_release_linear_copy(self._ctx), "release_linear_copy")
