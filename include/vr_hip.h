@@ -190,9 +190,18 @@ int vr_hip_download_volume(vr_ctx *ctx, void *host_out, uint64_t bytes);
  * (band b -> devices[b mod n]), every device renders its bands, the RGBA8 bands travel to devices[0] over xGMI — RCCL
  * ncclSend / ncclRecv (communicators from ncclCommInitAll; librccl is loaded on demand) or peer copies when RCCL is not
  * available or a device is listed twice — and a copy kernel there de-interleaves them.  `params` describe the WHOLE frame
- * (partition fields are ignored); the image equals the single-device image byte for byte.  Calls are synchronous.
+ * (partition fields are ignored); the image equals the single-device image byte for byte.
+ * vr_hip_multi_render / _render_device are synchronous, like every renderer call of the reference.  _render_device_async queues
+ * a frame and returns: two frames are in flight (band buffers, staging and events exist twice; nothing is created per frame),
+ * frame i+1 renders while the bands of frame i travel; `consumer_stream` (hipStream_t on devices[0], may be NULL) is made to wait
+ * for the assembled frame; vr_hip_multi_sync waits for everything queued.
  * A one-entry list is the single-device path.  The reference's `renderers[id]->render_volume()` reaches this through
- * volr::HipRenderer's device-list constructor (volume-rendering_amd/csrc/host/Renderer.h). */
+ * volr::HipRenderer's device-list constructor (volume-rendering_amd/csrc/host/Renderer.h).
+ * VERIFICATION STATE: with DISTINCT devices the RCCL / peer-copy transfer has not run on hardware yet (one-GPU build box); the
+ * split, the gather by copies, the assemble kernel and the pipeline run with lists that repeat device 0, and the RCCL calls run
+ * with VR_MULTI_TRANSPORT=rccl-self (one communicator, peer = self).  Therefore the first frame after every set_window on
+ * distinct devices is self-checked on devices[0] (its own render of the other ranks' bands against what arrived; VR_ERR_HIP
+ * "gather self-check failed" on a mismatch; VR_MULTI_SELFCHECK=0 disables, =1 forces it for any list). */
 typedef struct vr_multi vr_multi;
 int  vr_hip_multi_create(int n, const int *devices, vr_multi **out);
 void vr_hip_multi_destroy(vr_multi *m);
@@ -206,6 +215,9 @@ int  vr_hip_multi_set_volume(vr_multi *m, const void *host_voxels, uint32_t dim_
 int  vr_hip_multi_generate_volume(vr_multi *m, uint32_t kind, uint32_t n, uint32_t seed, uint32_t bytes_per_voxel);
 int  vr_hip_multi_render(vr_multi *m, const vr_params *params, uint8_t *host_rgba);           /* whole frame -> host buffer */
 int  vr_hip_multi_render_device(vr_multi *m, const vr_params *params, void *dev_rgba);        /* whole frame -> buffer on devices[0] */
+int  vr_hip_multi_render_device_async(vr_multi *m, const vr_params *params, void *dev_rgba, void *consumer_stream);
+int  vr_hip_multi_sync(vr_multi *m);
+int  vr_hip_multi_prepare(vr_multi *m, uint32_t copies);                                      /* vr_hip_prepare on every device */
 int  vr_hip_multi_timing(vr_multi *m, float *per_device_kernel_ms, float *total_ms);
 /* the partition itself: frame row y belongs to device *rank_out and is row *local_row_out of that device's band buffer */
 void vr_hip_multi_band_map(uint32_t n, uint32_t band_rows, uint32_t y, uint32_t *rank_out, uint32_t *local_row_out);

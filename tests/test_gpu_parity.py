@@ -327,6 +327,53 @@ def test_multi_device_frame_equals_single_device(vr, gpu, golden):
                 m.close()
 
 
+def test_multi_device_pipeline_rccl_self_and_selfcheck(vr, gpu, golden, monkeypatch):
+    """The parts of the several-GPU path that one GPU can execute:
+    * two frames in flight (vr_hip_multi_render_device_async / _sync): 8 different frames queued back to back into 8 buffers —
+      every one equals the single-device frame, so no band buffer of frame i was overwritten by frame i+1 or i+2;
+    * VR_MULTI_TRANSPORT=rccl-self: the bands travel through ncclSend / ncclRecv (one communicator, peer = self) — dlopen of
+      librccl, ncclCommInitAll, the grouped calls and their stream ordering run on hardware;
+    * VR_MULTI_SELFCHECK=1: the first-frame self-check (device 0's own render of the other ranks' bands against what arrived)
+      passes on a correct gather."""
+    import torch
+    case = [c for c in golden.cases(True) if c["label"] == "bench256_view5_default"][0]
+    st = load_volume(gpu, golden, case["volume"])
+    W = H = 256
+    gpu.set_window_buffer(W, H)
+    scene_params = [golden.params(case, s) for s in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR)]
+    frames = []
+    for i in range(8):                                    # 8 different frames: 4 views x 2 sampling modes of the same scene
+        p = scene_params[i & 1].copy()
+        p.view = vr.benchmark_view(W, H, (i >> 1) + 4 * (i & 1))
+        frames.append((p, gpu.render_volume(vr.whole_frame(p.copy()))))
+    for transport, selfcheck, devices in (("peer", "1", [0, 0, 0]), ("rccl-self", "1", [0, 0]), ("rccl-self", "0", [0, 0, 0, 0])):
+        monkeypatch.setenv("VR_MULTI_TRANSPORT", transport)
+        monkeypatch.setenv("VR_MULTI_SELFCHECK", selfcheck)
+        m = vr.MultiRenderer(devices)
+        try:
+            assert m.transport == ("peer-copy" if transport == "peer" else "rccl-self")
+            m.set_window_buffer(W, H)
+            m.set_transfer_fn(st["tf"], st["esl"])
+            m.set_volume(golden.voxels(case["volume"]))
+            m.prepare()
+            outs = [torch.full((H, W, 4), 7, dtype=torch.uint8, device="cuda:0") for _ in frames]
+            torch.cuda.synchronize()
+            consumer = torch.cuda.Stream()
+            for (p, _), out in zip(frames, outs):
+                m.render_volume_device_async(p, out.data_ptr(), consumer.cuda_stream)
+            with torch.cuda.stream(consumer):             # ordered behind the LAST frame by consumer_stream alone, no host sync yet
+                last = outs[-1].clone()
+            m.sync()
+            consumer.synchronize()
+            for i, ((_, want), out) in enumerate(zip(frames, outs)):
+                assert np.array_equal(out.cpu().numpy(), want), (transport, devices, i)
+            assert np.array_equal(last.cpu().numpy(), frames[-1][1])
+            per, total = m.timing()
+            assert all(x > 0 for x in per) and total > 0
+        finally:
+            m.close()
+
+
 def test_volume_info_and_release_of_the_linear_copy(vr, golden):
     """Brick copies are built on first use (or by vr_hip_prepare) and vr_hip_volume_info reports them; after
     vr_hip_release_linear_copy rendering is unchanged and everything that needs the linear array says so instead of reading

@@ -120,6 +120,9 @@ def lib():
         "vr_hip_multi_render": (C.c_int, [vp, P(VrParams), vp]),
         "vr_hip_multi_render_device": (C.c_int, [vp, P(VrParams), vp]),
         "vr_hip_multi_timing": (C.c_int, [vp, f32p, f32p]),
+        "vr_hip_multi_render_device_async": (C.c_int, [vp, P(VrParams), vp, vp]),
+        "vr_hip_multi_sync": (C.c_int, [vp]),
+        "vr_hip_multi_prepare": (C.c_int, [vp, u32]),
         "vr_hip_multi_band_map": (None, [u32, u32, u32, P(u32), P(u32)]),
         "vr_hip_multi_default_band_rows": (u32, [u32, u32]),
         "vr_host_benchmark_view": (C.c_int, [u32, u32, u32, f32p, C.c_float, P(VrView)]),

@@ -214,6 +214,26 @@ class MultiRenderer:
     def render_volume_device(self, params, dev_ptr):
         self._check(self._L.vr_hip_multi_render_device(self._m, C.byref(params), C.c_void_p(dev_ptr)), "render_volume_device")
 
+    def render_volume_device_async(self, params, dev_ptr, consumer_stream=None):
+        """Queues a frame (two in flight); `consumer_stream` (raw hipStream_t on devices[0]) waits for the assembled frame."""
+        self._check(self._L.vr_hip_multi_render_device_async(self._m, C.byref(params), C.c_void_p(dev_ptr),
+                                                             C.c_void_p(consumer_stream) if consumer_stream else None), "render_volume_device_async")
+
+    def sync(self):
+        self._check(self._L.vr_hip_multi_sync(self._m), "sync")
+
+    def prepare(self, copies=63):
+        self._check(self._L.vr_hip_multi_prepare(self._m, int(copies)), "prepare")
+
+    def context_timing(self, rank):
+        """vr_timing of one device's context (kernel_ms_sum / launches since its last reset)."""
+        from .binding import VrTiming
+        t = VrTiming()
+        rc = self._L.vr_hip_timing(C.c_void_p(self._L.vr_hip_multi_context(self._m, rank)), C.byref(t))
+        if rc:
+            raise VrError(rc, "vr_hip_timing")
+        return t
+
     def timing(self):
         per = (C.c_float * len(self.devices))()
         total = C.c_float()
