@@ -154,6 +154,14 @@ int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
  * (tests force every combination and compare the images).  No reference counterpart. */
 int vr_hip_set_tile_mapping(vr_ctx *ctx, int32_t lane_map, uint32_t phase_x, uint32_t phase_y);
 
+/* In which order the screen tiles of a frame are started: 1 (default) = measured-cost order — the first frame with a given set of
+ * parameters records what every tile cost (its longest wavefront), a small kernel behind it sorts the tiles, and later frames with
+ * the same parameters start their most expensive tiles first, so that a few long tiles (rays that probe along a block face, deep
+ * rays next to early-terminated ones) no longer form the tail of the frame; applied only while empty-space leaping or early ray
+ * termination is on (the full march has no tail).  0 = tile number = workgroup id, always.  Placement only: images are identical.
+ * No reference counterpart (its 16x16 blocks are started in grid order, GPURenderer1.cu:81-82,108). */
+int vr_hip_set_tile_scheduling(vr_ctx *ctx, uint32_t mode);
+
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
  *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.

@@ -27,12 +27,14 @@ def main():
     ap.add_argument("--bpv", type=int, default=1, help="bytes per voxel of the generated volume")
     ap.add_argument("--tile-map", default="", help="lane_map,phase_x,phase_y (default: automatic)")
     ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz, 3 / 4 run bricks along z / y")
+    ap.add_argument("--sched", type=int, default=1, help="vr_hip_set_tile_scheduling: 0 workgroup order, 1 measured-cost order")
     ap.add_argument("--wide", type=int, default=0, help="vr_hip_set_wide_addressing value (2: 64-bit z tables, 1024-thread workgroups)")
     a = ap.parse_args()
     vr = importlib.import_module("volume-rendering_amd")
     r = vr.HipRenderer(0)
     r.set_layout(vr.LAYOUT_BRICKED if a.layout == "bricked" else vr.LAYOUT_LINEAR)
     r.set_brick_plane(a.plane)
+    r.set_tile_scheduling(a.sched)
     if a.wide:
         r.set_wide_addressing(a.wide)
     if a.tile_map:
@@ -51,7 +53,8 @@ def main():
     res = {}
     for v in [int(x) for x in a.views.split(",")]:
         p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
-        r.render_volume_device(p, buf.data_ptr(), stream)
+        for _ in range(2):                                   # builds the brick copy; records the tile costs / builds the launch order
+            r.render_volume_device(p, buf.data_ptr(), stream)
         torch.cuda.synchronize()
         r.timing_reset()
         for _ in range(a.reps):
@@ -59,7 +62,7 @@ def main():
         torch.cuda.synchronize()
         t = r.timing()
         res[v] = round(t.kernel_ms_sum / t.launches, 4)
-    print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "layout": a.layout, "light": a.light,
+    print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "layout": a.layout, "light": a.light, "sched": a.sched,
                       "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4)}))
 
 

@@ -298,6 +298,44 @@ def test_set_volume_from_device_memory(vr, gpu, golden):
     assert np.array_equal(gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST)), golden.frame(case))
 
 
+def test_tile_scheduling_is_placement_only(vr, gpu, oracle):
+    """Measured-cost launch order (vr_hip_set_tile_scheduling 1, the default): the first frame with a set of parameters records the
+    cost of every tile, later frames start their most expensive tiles first.  Every frame — recording, ordered, ordered from
+    another stream — equals the frame rendered in plain workgroup order and the oracle's, in both sampling modes, for a frame
+    with a ragged tile grid; and the full march (no ESL, threshold 1) never uses an order."""
+    import torch
+    vox = oracle.generate_volume("shell", 64, 1)
+    tf, esl, bd, bs, step = oracle.scene_for(vox)
+    gpu.set_transfer_fn(tf, esl)
+    gpu.set_volume(vox)
+    W, H = 500, 333                                       # 16 x 21 tiles of 32x16 pixels, ragged on both sides
+    gpu.set_window_buffer(W, H)
+    try:
+        for view_i in (1, 3, 6):
+            for samp in (vr.SAMPLE_NEAREST, vr.SAMPLE_TRILINEAR):
+                p = vr.VrParams()
+                p.view = vr.benchmark_view(W, H, view_i)
+                p.ray_step, p.ray_threshold, p.esl, p.esl_block_dims, p.light_kd, p.sampling = float(step), 0.95, 1, bd, 0.6, samp
+                for j in range(3):
+                    p.esl_block_size[j] = float(bs[j])
+                vr.whole_frame(p)
+                want = oracle.render(p, vox, tf, esl)
+                gpu.set_tile_scheduling(0)
+                assert np.array_equal(gpu.render_volume(p), want)
+                gpu.set_tile_scheduling(1)
+                frames = [gpu.render_volume(p) for _ in range(3)]          # recording frame, then two ordered frames
+                assert all(np.array_equal(f, want) for f in frames), (view_i, samp)
+                # an ordered frame on ANOTHER stream than the one the order was built on
+                dev = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+                other = torch.cuda.Stream()
+                torch.cuda.synchronize()
+                gpu.render_volume_device(p, dev.data_ptr(), other.cuda_stream)
+                other.synchronize()
+                assert np.array_equal(dev.cpu().numpy(), want), (view_i, samp)
+    finally:
+        gpu.set_tile_scheduling(1)
+
+
 def test_multi_device_frame_equals_single_device(vr, gpu, golden):
     """vr_hip_multi_*: one call, several per-device contexts, interleaved bands gathered on devices[0] and de-interleaved there.
     On a one-GPU box the list names device 0 once (the single path), twice and three times (band split + peer-copy gather +

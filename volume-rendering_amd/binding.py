@@ -95,6 +95,7 @@ def lib():
         "vr_hip_set_wide_addressing": (C.c_int, [vp, u32]),
         "vr_hip_set_tile_mapping": (C.c_int, [vp, C.c_int32, u32, u32]),
         "vr_hip_set_brick_plane": (C.c_int, [vp, C.c_int32]),
+        "vr_hip_set_tile_scheduling": (C.c_int, [vp, u32]),
         "vr_hip_render": (C.c_int, [vp, P(VrParams), vp]),
         "vr_hip_render_device": (C.c_int, [vp, P(VrParams), vp, vp]),
         "vr_hip_timing": (C.c_int, [vp, P(VrTiming)]),

@@ -43,7 +43,8 @@ struct RayKernelArgs {
 	float    tf_zero_below;            // entries 0..tf_zero_below of the premultiplied TF are exactly (0,0,0,0); -1 if entry 0 is not
 	uint32_t skip_mask;                // per-voxel bit mask ~(skip_below - 1), replicated over the packed word: all 8 corners below the
 	                                   // power of two skip_below => TF coordinate <= tf_zero_below
-	uint32_t skip_never;               // 1 when the TF has no leading zero entries (the corner test must always fail), else 0
+	uint32_t skip_cmp;                 // the corner test is (corners & skip_mask) != skip_cmp: 0 normally; a TF with no leading zero entries
+	                                   // (no sample may take the shortcut) sets skip_mask = 0, skip_cmp = 1 — the test then always holds
 	uint32_t clamp_fetch;              // 1: clamp the fetch coordinates of every sample (views whose fp32 coordinates may leave (-1, N),
 	                                   // ray steps so long that two of them leave the table padding)
 	uint32_t near_scaled;              // 1: every edge is a power of two — NEAREST may march in the scaled domain (sample_nearest_scaled)
@@ -53,6 +54,9 @@ struct RayKernelArgs {
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
+// measured-cost launch order of a frame (vr_kernels.hip tile_order_kernel): order = workgroup id -> tile number or NULL (identity);
+// cost = per tile, the longest wave of the tile in 64-cycle units, or NULL (not recorded)
+struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr; };
 
 // TRILINEAR volume layouts.
 //   kLayoutLinear : the reference's x-fastest array (+ zeroed tail slack); a sample = 4 two-voxel loads at VOXEL
@@ -150,9 +154,14 @@ inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 // brick_plane, or the run bricks) or NULL (VR_LAYOUT_LINEAR).
 hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bytes_per_voxel,
                            const float *tf_premult /* 128 x float4 */, const uint32_t *esl_bits /* 1024 */,
-                           void *out_rgba, hipStream_t stream);
+                           void *out_rgba, TileSchedule sched, hipStream_t stream);
 
-bool raymarch_reads_linear(const RayKernelArgs &a, bool have_bricked, uint32_t bytes_per_voxel);
+// what launch_raymarch will do with these arguments: whether the variant reads the LINEAR array (refused once that was released),
+// and its grid of workgroup tiles (32x16 pixels, 32x32 for the 64-bit address tables)
+struct RaymarchPlan { bool reads_linear; uint32_t tiles_x, tiles_y; };
+RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t bytes_per_voxel);
+// cost[ntiles] (recorded by a frame) -> order[ntiles] for the next frame with the same parameters; clears cost
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t ntiles, hipStream_t stream);
 
 hipError_t launch_minmax(const void *volume, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                          uint32_t esl_block_dims, uint8_t *minmax_dev /* 32768 x {min,max} */, hipStream_t stream);

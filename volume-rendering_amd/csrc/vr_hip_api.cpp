@@ -56,8 +56,14 @@ struct vr_ctx {
 	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
 	uint32_t tile_phase_x = 0, tile_phase_y = 0;
 	// the last few automatic choices, keyed by the frame parameters and the volume size (a benchmark cycles 8 views)
-	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille; };
+	// Each entry also carries the measured-cost launch order of its frame (vr_kernels.hip tile_order_kernel): the first frame with
+	// these parameters records what every tile cost, the order kernel runs behind it on the same stream, later frames launch their
+	// tiles most expensive first.  order_state: 0 nothing yet, 1 = `order` is valid for `order_tiles` tiles.
+	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille;
+	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0, order_state = 0, order_layout = 0;
+	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
+	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -89,6 +95,7 @@ int fail(vr_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 	} while (0)
 
 bool copy_possible(const vr_ctx *c, uint32_t kind);
+hipError_t drain(vr_ctx *c);
 const void *copy_for(vr_ctx *c, uint32_t kind);
 
 bool finite3(const float *v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
@@ -248,8 +255,8 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		const uint32_t top = c->bpv == 1 ? 256u : 65536u;
 		for (uint32_t P = 1; P <= top; P <<= 1)
 			if (c->tf_zero_below >= 0.0f && std::fmaf((float) P, a.tf_scale, -0.5f) <= c->tf_zero_below) below = P;
-		a.skip_never = below == 0 ? 1u : 0u;
-		if (below == 0) a.skip_mask = 0xffffffffu;
+		a.skip_cmp = below == 0 ? 1u : 0u;
+		if (below == 0) a.skip_mask = 0u;
 		else if (c->bpv == 1) a.skip_mask = ((0xffu & ~(below - 1u)) * 0x01010101u);
 		else a.skip_mask = ((0xffffu & ~(below - 1u)) * 0x00010001u);
 	}
@@ -329,15 +336,16 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		else { a.esl_div_magic = (uint32_t) ((1ull << 32) / bd + 1); a.esl_div_shift = 0; }
 	}
 
+	vr_ctx::MapEntry *hit = nullptr;
 	if (c->tile_lane_map >= 0) { a.lane_map = (uint32_t) c->tile_lane_map; a.phase_x = c->tile_phase_x; a.phase_y = c->tile_phase_y; }
 	else {
-		vr_ctx::MapEntry *hit = nullptr;
 		for (uint32_t i = 0; i < c->map_cached && hit == nullptr; i++)
 			if (memcmp(&c->map_cache[i].p, p, sizeof *p) == 0 && memcmp(c->map_cache[i].dim, c->dim, sizeof c->dim) == 0) hit = &c->map_cache[i];
 		if (hit == nullptr) {
 			const uint32_t straddle = choose_tile_mapping(a);
 			hit = &c->map_cache[c->map_next];
 			hit->straddle_permille = straddle;
+			hit->order_state = 0;                        // the recycled entry's launch order belonged to other parameters
 			c->map_next = (c->map_next + 1) % 16u;
 			if (c->map_cached < 16u) c->map_cached++;
 			hit->p = *p; memcpy(hit->dim, c->dim, sizeof c->dim);
@@ -367,17 +375,49 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			else a.layout = kLayoutLinear;
 		}
 	}
-	if (raymarch_reads_linear(a, brick_copy != nullptr, c->bpv) && c->vol == nullptr)
+	const RaymarchPlan plan = plan_raymarch(a, brick_copy != nullptr, c->bpv);
+	if (plan.reads_linear && c->vol == nullptr)
 		return fail(c, VR_ERR_NOT_READY, "this frame needs the linear array, which was released (vr_hip_release_linear_copy): no resident brick copy "
 		                                 "serves this sampling mode / addressing path — prepare it before releasing, or set the volume again");
+
+	// Measured-cost launch order: only where rays differ in length (empty-space leaping or early termination on) — the full
+	// march has no tail to remove and keeps its cache-friendly tile numbering.
+	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
+	bool record = false;
+	TileSchedule sched;
+	if (hit != nullptr && c->tile_scheduling == 1 && (p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
+		if (hit->order_state == 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
+		if (hit->order_state == 1) {
+			// built on another stream: this frame must not read the order before the kernel that writes it has run
+			if (stream != hit->order_stream) VR_TRY(c, hipStreamWaitEvent(stream, hit->order_ready, 0));
+			sched.order = hit->order;
+		} else {
+			if (hit->capacity < ntiles) {
+				if (hit->cost) { VR_TRY(c, drain(c)); (void) hipFree(hit->cost); (void) hipFree(hit->order); hit->cost = hit->order = nullptr; hit->capacity = 0; }
+				if (hipMalloc((void **) &hit->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &hit->order, (size_t) ntiles * 4) == hipSuccess) hit->capacity = ntiles;
+				else { (void) hipGetLastError(); if (hit->cost) (void) hipFree(hit->cost); hit->cost = hit->order = nullptr; }
+			}
+			if (hit->capacity >= ntiles) {
+				VR_TRY(c, hipMemsetAsync(hit->cost, 0, (size_t) ntiles * 4, stream));
+				sched.cost = hit->cost;
+				record = true;
+			}
+		}
+	}
 
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
 	VR_TRY(c, hipEventRecord(ev.start, stream));
-	VR_TRY(c, launch_raymarch(a, c->vol, brick_copy, c->bpv, c->tf, c->esl, dev_rgba, stream));
+	VR_TRY(c, launch_raymarch(a, c->vol, brick_copy, c->bpv, c->tf, c->esl, dev_rgba, sched, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
+	if (record) {                                // behind the frame, on its stream: the next frame with these parameters is ordered
+		VR_TRY(c, launch_tile_order(hit->cost, hit->order, ntiles, stream));
+		if (hit->order_ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&hit->order_ready, hipEventDisableTiming));
+		VR_TRY(c, hipEventRecord(hit->order_ready, stream));
+		hit->order_state = 1; hit->order_tiles = ntiles; hit->order_layout = a.layout; hit->order_stream = stream;
+	}
 	return VR_OK;
 }
 
@@ -519,6 +559,7 @@ void vr_hip_destroy(vr_ctx *c) {
 	}
 	if (c->aux_start) (void) hipEventDestroy(c->aux_start);
 	if (c->aux_stop) (void) hipEventDestroy(c->aux_stop);
+	for (auto &e : c->map_cache) { if (e.cost) (void) hipFree(e.cost); if (e.order) (void) hipFree(e.order); if (e.order_ready) (void) hipEventDestroy(e.order_ready); }
 	if (c->fb) (void) hipFree(c->fb);
 	if (c->tf) (void) hipFree(c->tf);
 	if (c->esl) (void) hipFree(c->esl);
@@ -625,6 +666,14 @@ int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (plane < -1 || plane > (int32_t) kPlanes + 1) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z) or 4 (run bricks along y)");
 	c->brick_plane_force = plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane
+	return VR_OK;
+}
+
+int vr_hip_set_tile_scheduling(vr_ctx *c, uint32_t mode) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (mode > 1u) return fail(c, VR_ERR_INVALID, "tile scheduling mode must be 0 (workgroup id) or 1 (measured-cost order)");
+	c->tile_scheduling = mode;
+	for (auto &e : c->map_cache) e.order_state = 0;
 	return VR_OK;
 }
 

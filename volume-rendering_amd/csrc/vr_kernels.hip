@@ -56,6 +56,8 @@ struct __attribute__((aligned(16))) LdsTables {
 //               that two workgroups per CU still reach the 32-wave limit next to 56 KiB of tables each
 //   kAddrWide : full 64-bit index arithmetic, no tables (anything larger; also the linear layout beyond 4 GiB)
 enum : int { kAddr32 = 0, kAddrLut64 = 1, kAddrWide = 2 };
+// s_getreg_b32 operand: register HW_REG_HW_ID (4), offset 0, 6 bits = wave_id[3:0] | simd_id[5:4]
+constexpr int kHwIdWaveSimd = ((6 - 1) << 11) | (0 << 6) | 4;
 
 // Brick address tables at FIXED LDS positions, so a lookup is one shift + one ds_read with an immediate offset:
 // z entries first ({offset(z), offset(min(z+1, Z-1))} pairs: one ds_read_b64 / b128 serves both slices), then x, then y.
@@ -453,7 +455,21 @@ template <int I> __device__ __forceinline__ void managed_wait() {       // s_wai
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
 __global__ __launch_bounds__(LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)>::threads)
 void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const float *__restrict__ tf_g,
-                     const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out) {
+                     const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ out,
+                     const uint32_t *__restrict__ tile_order, uint32_t *__restrict__ tile_cost) {
+	// tile_order: workgroup id -> tile number (measured-cost launch order), or NULL: identity.  tile_cost: per tile, the longest wave of
+	// the tile in 64-cycle units (atomicMax), or NULL: not recorded.  Both are consumed FIRST, before the tables are staged: the hot
+	// variants sit at the 80-SGPR limit of 8 waves per SIMD and their peak is the staging code, so nothing of the schedule may be live
+	// there or during the march — the wave's start time and the address of its tile's cost word wait in LDS for the end of the wave.
+	// The LDS slot of a wave is its hardware slot on the CU (HW_ID: SIMD id, wave id — unique among the resident waves of a CU, hence
+	// of a workgroup, and readable again at the end without keeping threadIdx or a lane mask alive).
+	__shared__ uint32_t wave_sched[64][4];
+	const uint32_t tile_of_group = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
+	if ((threadIdx.x & 63u) == 0) {
+		const uint64_t slot = tile_cost ? (uint64_t) (uintptr_t) (tile_cost + tile_of_group) : 0ull;
+		uint32_t *w = wave_sched[__builtin_amdgcn_s_getreg(kHwIdWaveSimd)];
+		w[0] = (uint32_t) (__builtin_readcyclecounter() >> 6); w[1] = (uint32_t) slot; w[2] = (uint32_t) (slot >> 32);
+	}
 	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
 	constexpr bool kUseLut = L::max_dim != 0;
@@ -537,7 +553,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t bid = blockIdx.x;
 	const uint32_t full_cols = a.tiles_x / B, full_rows = a.tiles_y / B;
 	const uint32_t nblocked = full_cols * full_rows * B * B;          // tiles that lie in complete BxB blocks
-	uint32_t tile = bid;
+	uint32_t tile = tile_of_group;                                    // measured-cost launch order, or the workgroup id
 	if (VR_XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
 		const uint32_t xcd = bid & 7u, slot = bid >> 3, q = ntiles >> 3, r = ntiles & 7u;
 		tile = xcd * q + (xcd < r ? xcd : r) + slot;
@@ -759,7 +775,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				return tri_issue<BPV, ADDR, LAYOUT, true>(vol, a, lut, VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), kClamp);
 			};
 			constexpr bool kManaged = ManagedTri<BPV, ADDR, LAYOUT>::value;
-			const uint64_t skip_never = a.skip_never ? ~0ull : 0ull;
 			// Lane liveness is kept as ONE 64-bit wave mask in scalar registers (`live`), updated with v_cmp results
 			// (__builtin_amdgcn_fcmpf returns the wave's compare mask) — no per-lane control flow, no mask <-> VGPR round trips:
 			// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
@@ -808,7 +823,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				uint32_t corners;
 				if (LAYOUT != kLayoutLinear) corners = BPV == 1 ? (now.w0 | now.w1) : (now.w0 | now.w1 | now.w2 | now.w3);
 				else                          corners = now.w0 | now.w1 | now.w2 | now.w3;
-				if (((__builtin_amdgcn_uicmp(corners & a.skip_mask, 0u, kIcmpNE) | skip_never) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+				// skip_cmp is 0; a TF without leading zero entries (nothing may be skipped) comes with skip_mask 0 and skip_cmp 1: 0 != 1 always
+				if ((__builtin_amdgcn_uicmp(corners & a.skip_mask, a.skip_cmp, kIcmpNE) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);       // where the words were fetched
 				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(now, a, xb, yb, zb);                          // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
@@ -863,90 +879,150 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		       (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
 	}
 	*out_px = rgba;
+	// cost of the tile = its longest wave, in 64-cycle units (at least 1); written by the first lane that is still here
+	const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+	if (lane_id == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+		const uint32_t *w = wave_sched[__builtin_amdgcn_s_getreg(kHwIdWaveSimd)];
+		const uint64_t slot = ((uint64_t) w[2] << 32) | w[1];
+		if (slot != 0ull) atomicMax((uint32_t *) (uintptr_t) slot, ((uint32_t) (__builtin_readcyclecounter() >> 6) - w[0]) | 1u);
+	}
 }
 
-template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
-static hipError_t launch_variant(const RayKernelArgs &args, const void *volume, const float *tf, const uint32_t *esl,
-                                 void *out, hipStream_t stream) {
-	constexpr uint32_t threads = LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)>::threads;
-	RayKernelArgs a = args;
-	a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
-	a.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
-	// Run-brick frames are launched with 16 KiB of unused dynamic LDS: 3 instead of 4 workgroups per CU (24 waves).  Their waves
-	// touch ~10 cache lines per step, 32 of them overflow the 256 lines of the 32 KiB L1 between two steps and the L2 catches only a
-	// quarter of that reuse (measured: fabric requests -11 %, frame time -2 ... -5 % on those views; the VALU-bound quad-brick views
-	// need all 32 waves and lose 10 % with the same padding).  Not with empty-space leaping: those rays are short, the frame time is
-	// the tail of the few waves that probe a whole row of blocks, and fewer resident workgroups lengthen it (view 3: 1.53 -> 2.16 ms).
-	// VR_RUN_LDS_PAD=0 builds without it (A/B).
-#ifndef VR_RUN_LDS_PAD
-#define VR_RUN_LDS_PAD 16384
-#endif
-	#ifndef VR_PAD_LAYOUTS
-#define VR_PAD_LAYOUTS ((1u << kLayoutRun) | (1u << kLayoutRunY))
-#endif
-	const uint32_t dynamic_lds = ((VR_PAD_LAYOUTS >> LAYOUT) & 1u) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
-	hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
-	                   a, volume, tf, esl, (uint32_t *) out);
-	return hipGetLastError();
-}
-
-template <int SAMPLING, int BPV>
-static hipError_t launch_sampling(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
-                                  const uint32_t *esl, void *out, hipStream_t stream) {
+// Which instantiation a frame runs: ONE selector, visited by the launcher and by the host's questions about the launch (does it read
+// the linear array?  how many workgroup tiles?), so the answers cannot drift from what is launched.  `visit` is called with four
+// std::integral_constant tags <SAMPLING, BPV, ADDR, LAYOUT> and a bool: true = the variant reads `linear`, false = the brick copy.
+template <int SAMPLING, int BPV, class F>
+static auto select_sampling(const RayKernelArgs &a, bool have_bricked, F &&visit) {
 	constexpr bool nearest = SAMPLING == VR_SAMPLE_NEAREST;
+	typedef std::integral_constant<int, SAMPLING> S;
+	typedef std::integral_constant<int, BPV> V;
 	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
 	if constexpr (!nearest && BPV == 1) {
-		if (bricked != nullptr && a.layout == kLayoutRun)
-			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRun>(a, bricked, tf, esl, out, stream);
-		if (bricked != nullptr && a.layout == kLayoutRunY)
-			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutRunY>(a, bricked, tf, esl, out, stream);
+		if (have_bricked && a.layout == kLayoutRun)
+			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutRun>(), false);
+		if (have_bricked && a.layout == kLayoutRunY)
+			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutRunY>(), false);
 	}
 	if constexpr (nearest) {
-		if (bricked != nullptr && a.layout == kLayoutVoxel) {
+		if (have_bricked && a.layout == kLayoutVoxel) {
 			if (max_dim <= LutCfg<kAddr32>::max_dim && a.force_wide != 2)
-				return launch_variant<SAMPLING, BPV, kAddr32, kLayoutVoxel>(a, bricked, tf, esl, out, stream);
-			return launch_variant<SAMPLING, BPV, kAddrLut64, kLayoutVoxel>(a, bricked, tf, esl, out, stream);
+				return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutVoxel>(), false);
+			return visit(S(), V(), std::integral_constant<int, kAddrLut64>(), std::integral_constant<int, kLayoutVoxel>(), false);
 		}
 	}
-	if (bricked != nullptr) {
+	if (have_bricked && a.layout == kLayoutBricked) {
 		const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * BPV;
 		if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
-			return launch_variant<SAMPLING, BPV, kAddr32, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutBricked>(), false);
 		if (a.force_wide != 1 && max_dim <= LutCfg<kAddrLut64>::max_dim)
-			return launch_variant<SAMPLING, BPV, kAddrLut64, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return visit(S(), V(), std::integral_constant<int, kAddrLut64>(), std::integral_constant<int, kLayoutBricked>(), false);
 		if constexpr (!nearest)
-			return launch_variant<SAMPLING, BPV, kAddrWide, kLayoutBricked>(a, bricked, tf, esl, out, stream);
+			return visit(S(), V(), std::integral_constant<int, kAddrWide>(), std::integral_constant<int, kLayoutBricked>(), false);
 	}
 	// the reference's linear array; 32-bit byte offsets cover every volume the reference can express (ModelBase.h:12)
 	const bool wide = a.force_wide || ((uint64_t) a.dim_x * a.dim_y * a.dim_z + volume_tail_slack(a.dim_x, a.dim_y)) * BPV >= (1ull << 32);
-	return wide ? launch_variant<SAMPLING, BPV, kAddrWide, kLayoutLinear>(a, linear, tf, esl, out, stream)
-	            : launch_variant<SAMPLING, BPV, kAddr32, kLayoutLinear>(a, linear, tf, esl, out, stream);
+	return wide ? visit(S(), V(), std::integral_constant<int, kAddrWide>(), std::integral_constant<int, kLayoutLinear>(), true)
+	            : visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutLinear>(), true);
 }
 
-template <int BPV>
-static hipError_t launch_bpv(const RayKernelArgs &a, const void *linear, const void *bricked, const float *tf,
-                             const uint32_t *esl, void *out, hipStream_t stream) {
-	if (a.p.sampling == VR_SAMPLE_NEAREST) return launch_sampling<VR_SAMPLE_NEAREST, BPV>(a, linear, bricked, tf, esl, out, stream);
-	if (a.p.sampling == VR_SAMPLE_TRILINEAR_Q8) return launch_sampling<VR_SAMPLE_TRILINEAR_Q8, BPV>(a, linear, bricked, tf, esl, out, stream);
-	return launch_sampling<VR_SAMPLE_TRILINEAR, BPV>(a, linear, bricked, tf, esl, out, stream);
+template <class F>
+static auto select_variant(const RayKernelArgs &a, bool have_bricked, uint32_t bpv, F &&visit) {
+	if (bpv == 1) {
+		if (a.p.sampling == VR_SAMPLE_NEAREST) return select_sampling<VR_SAMPLE_NEAREST, 1>(a, have_bricked, visit);
+		if (a.p.sampling == VR_SAMPLE_TRILINEAR_Q8) return select_sampling<VR_SAMPLE_TRILINEAR_Q8, 1>(a, have_bricked, visit);
+		return select_sampling<VR_SAMPLE_TRILINEAR, 1>(a, have_bricked, visit);
+	}
+	if (a.p.sampling == VR_SAMPLE_NEAREST) return select_sampling<VR_SAMPLE_NEAREST, 2>(a, have_bricked, visit);
+	if (a.p.sampling == VR_SAMPLE_TRILINEAR_Q8) return select_sampling<VR_SAMPLE_TRILINEAR_Q8, 2>(a, have_bricked, visit);
+	return select_sampling<VR_SAMPLE_TRILINEAR, 2>(a, have_bricked, visit);
 }
 
-// Will launch_raymarch hand the LINEAR array to the kernel for these arguments?  Mirrors launch_sampling's dispatch: the host uses it
-// to refuse a frame whose variant would read a linear array that was released (vr_hip_release_linear_copy).
-bool raymarch_reads_linear(const RayKernelArgs &a, bool have_bricked, uint32_t bpv) {
-	if (!have_bricked) return true;
-	if (a.layout == kLayoutRun || a.layout == kLayoutRunY) return a.p.sampling == VR_SAMPLE_NEAREST || bpv != 1;
-	const uint32_t max_dim = a.dim_x > a.dim_y ? (a.dim_x > a.dim_z ? a.dim_x : a.dim_z) : (a.dim_y > a.dim_z ? a.dim_y : a.dim_z);
-	if (a.layout == kLayoutVoxel) return a.p.sampling != VR_SAMPLE_NEAREST;
-	const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 4 * bpv;
-	if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32)) return false;
-	if (a.force_wide != 1 && max_dim <= LutCfg<kAddrLut64>::max_dim) return false;
-	return a.p.sampling == VR_SAMPLE_NEAREST;            // index arithmetic: TRILINEAR has a bricked variant, NEAREST reads the linear array
+template <int ADDR, int LAYOUT> constexpr uint32_t variant_threads() { return LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)>::threads; }
+
+// what launch_raymarch will do with these arguments (launch_frame asks before it launches)
+RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t bpv) {
+	return select_variant(a, have_bricked, bpv, [&](auto, auto, auto addr, auto layout, bool reads_linear) {
+		constexpr uint32_t threads = variant_threads<decltype(addr)::value, decltype(layout)::value>();
+		RaymarchPlan plan;
+		plan.reads_linear = reads_linear;
+		plan.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
+		plan.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
+		return plan;
+	});
 }
 
-hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const void *bricked, uint32_t bpv, const float *tf,
-                           const uint32_t *esl, void *out, hipStream_t stream) {
-	return bpv == 1 ? launch_bpv<1>(a, linear, bricked, tf, esl, out, stream) : launch_bpv<2>(a, linear, bricked, tf, esl, out, stream);
+hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const void *bricked, uint32_t bpv, const float *tf,
+                           const uint32_t *esl, void *out, TileSchedule sched, hipStream_t stream) {
+	return select_variant(args, bricked != nullptr, bpv, [&](auto sampling, auto voxel, auto addr, auto layout, bool reads_linear) {
+		constexpr int SAMPLING = decltype(sampling)::value, BPV = decltype(voxel)::value, ADDR = decltype(addr)::value, LAYOUT = decltype(layout)::value;
+		constexpr uint32_t threads = variant_threads<ADDR, LAYOUT>();
+		RayKernelArgs a = args;
+		a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u;
+		a.tiles_y = (a.p.out_rows + a.phase_y + threads / 32u - 1u) / (threads / 32u);
+		// Run-brick frames are launched with 16 KiB of unused dynamic LDS: 3 instead of 4 workgroups per CU (24 waves).  Their waves
+		// touch ~10 cache lines per step, 32 of them overflow the 256 lines of the 32 KiB L1 between two steps and the L2 catches only a
+		// quarter of that reuse (measured: fabric requests -11 %, frame time -2 ... -5 % on those views; the VALU-bound quad-brick views
+		// need all 32 waves and lose 10 % with the same padding).  Not with empty-space leaping: those rays are short, the frame time is
+		// the tail of the few waves that probe a whole row of blocks, and fewer resident workgroups lengthen it (view 3: 1.53 -> 2.16 ms).
+		// VR_RUN_LDS_PAD=0 builds without it (A/B).
+#ifndef VR_RUN_LDS_PAD
+#define VR_RUN_LDS_PAD 16384
+#endif
+#ifndef VR_PAD_LAYOUTS
+#define VR_PAD_LAYOUTS ((1u << kLayoutRun) | (1u << kLayoutRunY))
+#endif
+		const uint32_t dynamic_lds = ((VR_PAD_LAYOUTS >> LAYOUT) & 1u) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
+		hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
+		                   a, reads_linear ? linear : bricked, tf, esl, (uint32_t *) out, sched.order, sched.cost);
+		return hipGetLastError();
+	});
+}
+
+// ---- measured-cost tile order -------------------------------------------------------------------------------------------------
+//
+// The hardware starts workgroups in id order as slots free up; rays of very different length (empty-space leaping, early
+// termination, rays that probe along a block face) make some tiles 10-50x longer than others, and a long tile that starts late
+// IS the tail of the frame.  A frame can record what every tile cost (tile_cost: the longest wave of the tile, in 64-cycle units);
+// this kernel turns that into a launch order for the next frame with the same parameters: tiles binned by cost into kOrderBins
+// bins, most expensive bin first, original tile order inside a bin (neighbouring tiles of similar cost stay neighbours: they share
+// cache lines).  One workgroup, a stable counting sort through LDS; clears the costs for the next recording.  Placement only.
+constexpr uint32_t kOrderBins = 16, kOrderThreads = 512;
+
+__global__ __launch_bounds__(kOrderThreads)
+void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t ntiles) {
+	__shared__ uint32_t count[kOrderBins][kOrderThreads + 1];
+	__shared__ uint32_t vmax;
+	const uint32_t t = threadIdx.x;
+	const uint32_t chunk = (ntiles + kOrderThreads - 1) / kOrderThreads, lo = t * chunk < ntiles ? t * chunk : ntiles, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+	if (t == 0) vmax = 0;
+	__syncthreads();
+	uint32_t m = 0;
+	for (uint32_t i = lo; i < hi; i++) m = cost[i] > m ? cost[i] : m;
+	atomicMax(&vmax, m);
+	__syncthreads();
+	const uint64_t top = (uint64_t) vmax + 1;
+	auto bin_of = [&](uint32_t c) { return kOrderBins - 1u - (uint32_t) (((uint64_t) c * kOrderBins) / top); };    // 0 = most expensive
+	uint32_t mine[kOrderBins];
+	for (uint32_t b = 0; b < kOrderBins; b++) mine[b] = 0;
+	for (uint32_t i = lo; i < hi; i++) mine[bin_of(cost[i])]++;
+	for (uint32_t b = 0; b < kOrderBins; b++) count[b][t] = mine[b];
+	__syncthreads();
+	if (t < kOrderBins) {                                   // exclusive scan of one bin's per-thread counts; total in the last slot
+		uint32_t run = 0;
+		for (uint32_t i = 0; i < kOrderThreads; i++) { const uint32_t c = count[t][i]; count[t][i] = run; run += c; }
+		count[t][kOrderThreads] = run;
+	}
+	__syncthreads();
+	uint32_t base = 0, pos[kOrderBins];
+	for (uint32_t b = 0; b < kOrderBins; b++) { pos[b] = base + count[b][t]; base += count[b][kOrderThreads]; }
+	for (uint32_t i = lo; i < hi; i++) { order[pos[bin_of(cost[i])]++] = i; }
+	__syncthreads();
+	for (uint32_t i = lo; i < hi; i++) cost[i] = 0;
+}
+
+hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t ntiles, hipStream_t stream) {
+	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, ntiles);
+	return hipGetLastError();
 }
 
 // ---- linear -> bricked copy ------------------------------------------------------------------------------------------

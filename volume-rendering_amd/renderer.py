@@ -82,6 +82,10 @@ class HipRenderer:
         """Lane order inside a 4x4-pixel block (-1 automatic, 0 rows, 1 columns, 2 2x2 blocks) and tile-grid phase; speed only."""
         self._check(self._L.vr_hip_set_tile_mapping(self._ctx, int(lane_map), int(phase_x), int(phase_y)), "set_tile_mapping")
 
+    def set_tile_scheduling(self, mode=1):
+        """0: tile = workgroup id; 1 (default): measured-cost order for frames with ESL / ERT on (most expensive tiles first); speed only."""
+        self._check(self._L.vr_hip_set_tile_scheduling(self._ctx, int(mode)), "set_tile_scheduling")
+
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
         k = {"shell": 0, "noise": 1}[kind]
