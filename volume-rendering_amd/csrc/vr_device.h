@@ -16,12 +16,18 @@ constexpr uint32_t kMaxRaySteps = 1u << 22;
 // Software pipeline of the march: the gathers of sample i + kDepth are issued before sample i is consumed; the loop body is
 // instantiated once per fetch slot (kDepth + 1 of them, rotating roles — no register copies) and iteration.  A finished lane has
 // up to kDepth speculative fetches beyond its exit point, which the kLutPad repeated edge entries of the address tables absorb:
-// the host checks kDepth * (cells per step) + 1.5 <= kLutPad per frame and otherwise runs the coordinate-clamping variant.
+// the host checks kOverrunSteps * (cells per step) + 1.5 <= kLutPad per frame and otherwise runs the coordinate-clamping variant.
 #ifndef VR_DEPTH
 #define VR_DEPTH 4
 #endif
 constexpr int kDepth = VR_DEPTH, kSlots = kDepth + 1;
-constexpr int kLutPad = 10;
+// Lazy exit test (unclamped march): whether a lane has left its ray segment is tested once per rotation of the fetch slots (and by
+// every sample that composites), not per sample — a finished lane then marches up to kSlots further steps before its step becomes 0.
+#ifndef VR_LAZY_EXIT
+#define VR_LAZY_EXIT 1
+#endif
+constexpr int kOverrunSteps = kDepth + (VR_LAZY_EXIT ? kSlots : 0);     // steps a speculative fetch may lie beyond a ray's exit point
+constexpr int kLutPad = VR_LAZY_EXIT ? 17 : 10;
 static_assert(kDepth >= 1 && kDepth <= 6, "prefetch depth");
 
 // Everything the ray-march kernel reads that is not an array: passed BY VALUE as the kernel argument (the reference

@@ -283,7 +283,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 					d += std::fabs(p->view.right_plane[i]) * (0.5f * (float) p->view.width + 1.0f) + std::fabs(p->view.up_plane[i]) * (0.5f * (float) p->view.height + 1.0f);
 				advance = std::fmax(advance, d * half[i]);
 			}
-			if (!((float) kDepth * p->ray_step * advance + 1.5f <= (float) kLutPad)) a.clamp_fetch = 1u;
+			if (!((float) kOverrunSteps * p->ray_step * advance + 1.5f <= (float) kLutPad)) a.clamp_fetch = 1u;
 		}
 		if (c->force_clamp_fetch & 1u) a.clamp_fetch = 1u;
 		auto pow2 = [](uint32_t n) { return n != 0 && (n & (n - 1)) == 0; };
@@ -385,7 +385,10 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
 	bool record = false;
 	TileSchedule sched;
-	if (hit != nullptr && c->tile_scheduling == 1 && (p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
+#ifndef VR_ORDER_ALWAYS
+#define VR_ORDER_ALWAYS 0
+#endif
+	if (hit != nullptr && c->tile_scheduling == 1 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
 		if (hit->order_state == 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
 		if (hit->order_state == 1) {
 			// built on another stream: this frame must not read the order before the kernel that writes it has run

@@ -677,6 +677,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// the table padding.  Otherwise (no tables, or the clamping variant) every fetch position is taken at min(k, ky) / clamped.
 		constexpr bool kFree = !kClamp && kTables;
 		constexpr bool kScaled = kFree && decltype(scaled_tag)::value;               // sample_nearest_scaled
+		constexpr bool kLazy = kFree && VR_LAZY_EXIT;
 		const f3 so = kScaled ? mk3(origin.x * a.half_x, origin.y * a.half_y, origin.z * a.half_z) : origin;
 		const f3 sd = kScaled ? mk3(dir.x * a.half_x, dir.y * a.half_y, dir.z * a.half_z) : dir;
 		float step_v = kFree ? select_lanes(live, step) : step;
@@ -702,6 +703,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			__builtin_amdgcn_sched_barrier(0);
 			kx = ks[c];
 			const float kn = ks[nx];
+			(void) kn;
 			// Nothing that reads the fetched word may move above this point: the compiler otherwise hoists such work to the loop latch,
 			// behind an s_waitcnt vmcnt(0) that drains the prefetches in flight once per iteration.
 			if (kManaged) { pin(word[c]); managed_wait<kDepth>(); pin(word[c]); }
@@ -711,6 +713,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			// s <= opaque_above = (tf_zero_idx + 1) * TF_RATIO * (1 or 256) - 1: tested on the voxel itself, the index is only formed
 			// by the few samples that get past the test
 			if ((__builtin_amdgcn_sicmp((int) s, opaque_above, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+				if (kLazy) {                                                                      // this sample's own segment test (see the loop)
+					const uint64_t inside = __builtin_amdgcn_fcmpf(kx, ky, kFcmpOLE);
+					if ((live & ~inside) != 0ull) { live &= inside; step_v = select_lanes(live, step); }       // a lane that is dropped here stops HERE:
+				}                                                                                 // the rotation test only looks at lanes still marked live
 				uint32_t idx = (BPV == 1 ? s : (s >> 8)) / VR_TF_RATIO;
 				asm volatile("" : "+v"(idx));                                                       // keep the index arithmetic inside the branch
 				f4 cur = lds.tf[idx];
@@ -734,12 +740,23 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                      // CPURenderer.cpp:35-36
 				if (kFree) step_v = select_lanes(live, step);                                     // terminated rays stop marching
 			}
-			const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
-			if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);      // a lane has just left its segment
-			live &= still;
+			if (!kLazy) {
+				const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);
+				if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);      // a lane has just left its segment
+				live &= still;
+			}
 		};
-		while (live != 0ull)
+		// kLazy: `live` is brought up to date once per rotation of the slots (the k of the next sample against the end of the segment),
+		// and by every sample that composites, for itself.  In between a finished lane still counts as live: its fetches lie in the
+		// table padding (kOverrunSteps), a transparent sample does nothing with it, a compositing sample tests it first.
+		while (live != 0ull) {
 			static_for<0, kSlots>(step_sample);
+			if (kLazy) {
+				const uint64_t still = __builtin_amdgcn_fcmpf(ks[0], ky, kFcmpOLE);
+				if ((live & ~still) != 0ull) step_v = select_lanes(live & still, step);
+				live &= still;
+			}
+		}
 		if (kManaged) {                                              // nothing in flight into registers we release
 			static_for<0, kSlots>([&](auto j) { pin(word[j.value]); });
 			managed_wait<0>();
@@ -765,6 +782,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		auto march = [&](auto clamp_tag) {                    // instantiated for both settings: no per-sample test of the flag
 			constexpr bool kClamp = decltype(clamp_tag)::value;
 			constexpr bool kFree = !kClamp && kTables;        // see the NEAREST loop: no min(k, ky), finished lanes stop instead
+			constexpr bool kLazy = kFree && VR_LAZY_EXIT;     // exit test once per rotation of the slots (see the NEAREST loop)
 			// Software pipeline: the loads of sample i+2 are issued before sample i is
 			// unpacked, filtered and composited, so memory round trips overlap the arithmetic inside every wave (on top of the
 			// 8 waves per SIMD).  The body is written once (`step_sample`) and instantiated once per fetch slot and iteration
@@ -800,6 +818,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				TriFetch<BPV, LAYOUT> &cur = f[c];
 				kx = ks[c];
 				const float kn = ks[nx];
+				(void) kn;
+			(void) kn;
 				// Exact shortcuts, decided per wave.  Entries 0..tf_zero_below of the premultiplied TF are all zero (the reference's
 				// default TF is zero below 10 % density), so a sample whose TF coordinate tb is <= tf_zero_below has colour
 				// (0,0,0,0), is never shaded (alpha 0 <= 0.05) and leaves acc bit-for-bit unchanged.
@@ -825,6 +845,10 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				else                          corners = now.w0 | now.w1 | now.w2 | now.w3;
 				// skip_cmp is 0; a TF without leading zero entries (nothing may be skipped) comes with skip_mask 0 and skip_cmp 1: 0 != 1 always
 				if ((__builtin_amdgcn_uicmp(corners & a.skip_mask, a.skip_cmp, kIcmpNE) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+				if (kLazy) {
+					const uint64_t inside = __builtin_amdgcn_fcmpf(kx, ky, kFcmpOLE);
+					if ((live & ~inside) != 0ull) { live &= inside; step_v = select_lanes(live, step); }
+				}
 				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);       // where the words were fetched
 				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(now, a, xb, yb, zb);                          // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
@@ -856,12 +880,20 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					if (kFree) step_v = select_lanes(live, step);                                       // terminated rays stop marching
 				}
 				}
-				const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                        // the loop condition
-				if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);        // a lane has just left its segment
-				live &= still;
+				if (!kLazy) {
+					const uint64_t still = __builtin_amdgcn_fcmpf(kn, ky, kFcmpOLE);                    // the loop condition
+					if (kFree && (live & ~still) != 0ull) step_v = select_lanes(live & still, step);    // a lane has just left its segment
+					live &= still;
+				}
 			};
-			while (live != 0ull)
+			while (live != 0ull) {
 				static_for<0, kSlots>(step_sample);
+				if (kLazy) {
+					const uint64_t still = __builtin_amdgcn_fcmpf(ks[0], ky, kFcmpOLE);
+					if ((live & ~still) != 0ull) step_v = select_lanes(live & still, step);
+					live &= still;
+				}
+			}
 			if (kManaged) {                                            // nothing in flight into registers we release
 				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else if (BPV == 2) pin(f[j.value].q, f[j.value].q2); else pin(f[j.value].w0, f[j.value].w1); };
 				static_for<0, kSlots>(pin_slot);
@@ -986,7 +1018,10 @@ hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const 
 // this kernel turns that into a launch order for the next frame with the same parameters: tiles binned by cost into kOrderBins
 // bins, most expensive bin first, original tile order inside a bin (neighbouring tiles of similar cost stay neighbours: they share
 // cache lines).  One workgroup, a stable counting sort through LDS; clears the costs for the next recording.  Placement only.
-constexpr uint32_t kOrderBins = 16, kOrderThreads = 512;
+#ifndef VR_ORDER_BINS
+#define VR_ORDER_BINS 16
+#endif
+constexpr uint32_t kOrderBins = VR_ORDER_BINS, kOrderThreads = 512;
 
 __global__ __launch_bounds__(kOrderThreads)
 void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t ntiles) {
