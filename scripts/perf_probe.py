@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--bpv", type=int, default=1, help="bytes per voxel of the generated volume")
     ap.add_argument("--tile-map", default="", help="lane_map,phase_x,phase_y (default: automatic)")
     ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz, 3 / 4 run bricks along z / y")
+    ap.add_argument("--each", action="store_true", help="synchronise after every launch and list the kernel time of each")
     ap.add_argument("--sched", type=int, default=1, help="vr_hip_set_tile_scheduling: 0 workgroup order, 1 measured-cost order")
     ap.add_argument("--wide", type=int, default=0, help="vr_hip_set_wide_addressing value (2: 64-bit z tables, 1024-thread workgroups)")
     a = ap.parse_args()
@@ -50,20 +51,30 @@ def main():
     samp = {"trilinear": vr.SAMPLE_TRILINEAR, "q8": vr.SAMPLE_TRILINEAR_Q8}.get(a.sampling, vr.SAMPLE_NEAREST)
     buf = torch.empty((W, W, 4), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    res = {}
+    res, spread = {}, {}
     for v in [int(x) for x in a.views.split(",")]:
         p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
         for _ in range(2):                                   # builds the brick copy; records the tile costs / builds the launch order
             r.render_volume_device(p, buf.data_ptr(), stream)
         torch.cuda.synchronize()
         r.timing_reset()
+        if a.each:                                           # every launch on its own: min / max of the kernel time
+            each = []
+            for _ in range(a.reps):
+                r.render_volume_device(p, buf.data_ptr(), stream)
+                torch.cuda.synchronize()
+                each.append(round(r.timing().kernel_ms, 4))
+            spread[v] = each
+            res[v] = round(sum(each) / len(each), 4)
+            continue
         for _ in range(a.reps):
             r.render_volume_device(p, buf.data_ptr(), stream)
         torch.cuda.synchronize()
         t = r.timing()
         res[v] = round(t.kernel_ms_sum / t.launches, 4)
     print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "layout": a.layout, "light": a.light, "sched": a.sched,
-                      "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4)}))
+                      "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4),
+                      **({"each": spread} if a.each else {})}))
 
 
 if __name__ == "__main__":

@@ -26,9 +26,14 @@ constexpr int kDepth = VR_DEPTH, kSlots = kDepth + 1;
 #ifndef VR_LAZY_EXIT
 #define VR_LAZY_EXIT 1
 #endif
-constexpr int kOverrunSteps = kDepth + (VR_LAZY_EXIT ? kSlots : 0);     // steps a speculative fetch may lie beyond a ray's exit point
-constexpr int kLutPad = VR_LAZY_EXIT ? 17 : 10;
-static_assert(kDepth >= 1 && kDepth <= 6, "prefetch depth");
+// prefetch depth of the run-brick variants (one 8-byte gather = two registers per slot)
+#ifndef VR_RUN_DEPTH
+#define VR_RUN_DEPTH VR_DEPTH
+#endif
+constexpr int kRunDepth = VR_RUN_DEPTH, kMaxDepth = kRunDepth > kDepth ? kRunDepth : kDepth;
+constexpr int kOverrunSteps = kMaxDepth + (VR_LAZY_EXIT ? kMaxDepth + 1 : 0);     // steps a speculative fetch may lie beyond a ray's exit point
+constexpr int kLutPad = (kOverrunSteps * 5 + 2) / 3 + 2;                          // >= kOverrunSteps * 1.666 (the reference's longest step, in cells) + 1.5
+static_assert(kDepth >= 1 && kDepth <= 6 && kRunDepth >= 1 && kRunDepth <= 12, "prefetch depth");
 
 // Everything the ray-march kernel reads that is not an array: passed BY VALUE as the kernel argument (the reference
 // does the same with its Raycaster POD, GPURenderer1.cu:30,108) so it lands in SGPRs via s_load from the kernarg segment.

@@ -58,7 +58,9 @@ struct vr_ctx {
 	// the last few automatic choices, keyed by the frame parameters and the volume size (a benchmark cycles 8 views)
 	// Each entry also carries the measured-cost launch order of its frame (vr_kernels.hip tile_order_kernel): the first frame with
 	// these parameters records what every tile cost, the order kernel runs behind it on the same stream, later frames launch their
-	// tiles most expensive first.  order_state: 0 nothing yet, 1 = `order` is valid for `order_tiles` tiles.
+	// tiles most expensive first.  order_state: 0 nothing yet, 1 or 2 = `order` is valid for `order_tiles` tiles; the frame that finds
+	// state 1 records once more (the very first frame of a view runs on cold caches and address translations, which makes its early
+	// tiles look expensive) and rebuilds the order behind itself; state 2 is final.
 	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille;
 	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0, order_state = 0, order_layout = 0;
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
@@ -389,15 +391,19 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 #define VR_ORDER_ALWAYS 0
 #endif
 	if (hit != nullptr && c->tile_scheduling == 1 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
-		if (hit->order_state == 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
-		if (hit->order_state == 1) {
+		if (hit->order_state >= 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
+		if (hit->order_state >= 1) {
 			// built on another stream: this frame must not read the order before the kernel that writes it has run
 			if (stream != hit->order_stream) VR_TRY(c, hipStreamWaitEvent(stream, hit->order_ready, 0));
-			sched.order = hit->order;
+			sched.order = hit->order + (hit->order_state == 2 ? hit->capacity : 0u);     // the second order lives in the second half: a frame
+			if (hit->order_state == 1 && stream == hit->order_stream) {                  // still running on another stream keeps reading the first          // second recording, under the first order (cost[] was cleared by the order kernel)
+				sched.cost = hit->cost;
+				record = true;
+			}
 		} else {
 			if (hit->capacity < ntiles) {
 				if (hit->cost) { VR_TRY(c, drain(c)); (void) hipFree(hit->cost); (void) hipFree(hit->order); hit->cost = hit->order = nullptr; hit->capacity = 0; }
-				if (hipMalloc((void **) &hit->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &hit->order, (size_t) ntiles * 4) == hipSuccess) hit->capacity = ntiles;
+				if (hipMalloc((void **) &hit->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &hit->order, (size_t) ntiles * 8) == hipSuccess) hit->capacity = ntiles;
 				else { (void) hipGetLastError(); if (hit->cost) (void) hipFree(hit->cost); hit->cost = hit->order = nullptr; }
 			}
 			if (hit->capacity >= ntiles) {
@@ -416,10 +422,10 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
 	if (record) {                                // behind the frame, on its stream: the next frame with these parameters is ordered
-		VR_TRY(c, launch_tile_order(hit->cost, hit->order, ntiles, stream));
+		VR_TRY(c, launch_tile_order(hit->cost, hit->order + (hit->order_state == 0 ? 0u : hit->capacity), ntiles, stream));
 		if (hit->order_ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&hit->order_ready, hipEventDisableTiming));
 		VR_TRY(c, hipEventRecord(hit->order_ready, stream));
-		hit->order_state = 1; hit->order_tiles = ntiles; hit->order_layout = a.layout; hit->order_stream = stream;
+		hit->order_state = hit->order_state == 0 ? 1 : 2; hit->order_tiles = ntiles; hit->order_layout = a.layout; hit->order_stream = stream;
 	}
 	return VR_OK;
 }

@@ -440,14 +440,8 @@ __device__ __forceinline__ void pin(uint32_t &x, uint32_t &y, uint32_t &z, uint3
 __device__ __forceinline__ void pin(uint64_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(uint64_t &x, uint64_t &y) { asm volatile("" : "+v"(x), "+v"(y)); }
 template <int I> __device__ __forceinline__ void managed_wait() {       // s_waitcnt vmcnt(I): all but the I youngest gathers have landed
-	static_assert(I >= 0 && I <= 15, "vmcnt");
-	if constexpr (I == 0) asm volatile("s_waitcnt vmcnt(0)"); else if constexpr (I == 1) asm volatile("s_waitcnt vmcnt(1)");
-	else if constexpr (I == 2) asm volatile("s_waitcnt vmcnt(2)"); else if constexpr (I == 3) asm volatile("s_waitcnt vmcnt(3)");
-	else if constexpr (I == 4) asm volatile("s_waitcnt vmcnt(4)"); else if constexpr (I == 5) asm volatile("s_waitcnt vmcnt(5)");
-	else if constexpr (I == 6) asm volatile("s_waitcnt vmcnt(6)"); else if constexpr (I == 7) asm volatile("s_waitcnt vmcnt(7)");
-	else if constexpr (I == 8) asm volatile("s_waitcnt vmcnt(8)"); else if constexpr (I == 9) asm volatile("s_waitcnt vmcnt(9)");
-	else if constexpr (I == 10) asm volatile("s_waitcnt vmcnt(10)"); else if constexpr (I == 11) asm volatile("s_waitcnt vmcnt(11)");
-	else if constexpr (I == 12) asm volatile("s_waitcnt vmcnt(12)"); else asm volatile("s_waitcnt vmcnt(13)");
+	static_assert(I >= 0 && I <= 63, "vmcnt is a 6-bit field on gfx9");
+	asm volatile("s_waitcnt vmcnt(%0)" : : "n"(I));
 }
 
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
@@ -800,7 +794,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			float step_v = kFree ? select_lanes(live, step) : step;       // per-lane step: 0 once the lane is finished
 			// kDepth samples ahead (one less for 2-byte voxels, whose slots hold four words: 64 VGPRs keep 8 waves per SIMD):
 			// slot j carries the fetched words and the k of its sample
-			constexpr int kDepth = BPV == 1 ? vr::kDepth : (vr::kDepth > 1 ? vr::kDepth - 1 : 1), kSlots = kDepth + 1;
+			constexpr int kDepth = is_run_layout(LAYOUT) ? kRunDepth : (BPV == 1 ? vr::kDepth : (vr::kDepth > 1 ? vr::kDepth - 1 : 1)), kSlots = kDepth + 1;
 			TriFetch<BPV, LAYOUT> f[kSlots]; float ks[kSlots];
 			ks[0] = kx;
 			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0; f[kSlots - 1].q2 = 0;
