@@ -3,7 +3,11 @@
 synthetic "shell" 1024^3 u8 volume (1 GiB, resident in HBM) rendered at 2048 x 2048, one frame per step, cycling
 through the reference's 8 benchmark views (2 projections x 4 poses at distance 2, VolR.cpp:225-253).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c2|c3|c4|c5] [--simulate-ranks 2,4,8]
+
+--config selects another BASELINE.json configuration for the timed region (c2 256^3 @ 1024^2, c3 512^3 @ 1920x1080, c4 = the default
+headline, c5 2048^3 uint16 @ 4096^2); at N = 1 the default run also reports c2 / c3 / c5, the linear layout on the headline workload,
+the reference's own host-buffer timed region and the N-rank load-balance model under `extras` / `scale_model`.
 
 With N > 1 and no torch.distributed environment the script starts N ranks of itself (one per GPU) through
 `python -m torch.distributed.run` and relays rank 0's JSON line; launched under torch.distributed.run directly
@@ -43,13 +47,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--volume", type=int, default=1024, help="cube edge of the synthetic shell volume")
-    ap.add_argument("--viewport", type=int, default=2048)
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c4", help="BASELINE.json configuration (c4 = the headline)")
+    ap.add_argument("--volume", type=int, default=0, help="cube edge of the synthetic shell volume (default: the configuration's)")
+    ap.add_argument("--viewport", type=int, default=0, help="viewport width (and height, unless --height is given)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--bytes-per-voxel", type=int, default=0, choices=(0, 1, 2))
+    ap.add_argument("--simulate-ranks", default="2,4,8", help="N = 1: rank counts of the load-balance model (scale_model); '' switches it off")
     ap.add_argument("--mode", choices=("nooptims", "default", "ertonly"), default="nooptims")
     ap.add_argument("--sampling", choices=("trilinear", "nearest"), default="trilinear")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras", default="modes,host,scale,configs,linear,multi",
+                    help="N = 1: which extra legs run after the timed region (other modes, host-buffer region, rank simulation, other configs, linear layout, several-device host overhead)")
     ap.add_argument("--cpu-band-rows", type=int, default=96, help="rows per view of the 1-core CPU-baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the multi-rank plumbing, nothing is rendered")
     ap.add_argument("--force-launcher", action="store_true", help="start the ranks as child processes even for --gpus 1")
@@ -214,7 +224,13 @@ def run_rank(a):
         return 2
     distributed = world > 1 or "RANK" in os.environ            # under torch.distributed.run even N=1 goes through the collective
     dmod = importlib.import_module("volume-rendering_amd.distributed")
-    n, W, H = a.volume, a.viewport, a.viewport
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_extras as bx
+    cn, cW, cH, cbpv = bx.CONFIGS[a.config]
+    n = a.volume or cn
+    W = a.viewport or cW
+    H = a.height or (a.viewport or cH)
+    bpv = a.bytes_per_voxel or cbpv
     band_rows = a.band_rows or dmod.default_band_rows(H, world)
     split = dmod.FrameSplit(W, H, world, rank, band_rows)
 
@@ -240,7 +256,8 @@ def run_rank(a):
         vr = importlib.import_module("volume-rendering_amd")
         r = vr.HipRenderer(local_rank)
         # -- scene: volume generated in HBM, ESL min/max by the streaming reduction, TF/ESL/ray_step by the host mirror
-        r.generate_volume("shell", n, seed=1)
+        t_setup = time.perf_counter()
+        r.generate_volume("shell", n, seed=1, bytes_per_voxel=bpv)
         minmax = r.volume_minmax()[0]
         minmax_ms = r.volume_minmax()[3]                        # second run: warm clocks
         scene = vr.Scene().set_volume(dims=(n, n, n), minmax=minmax)
@@ -249,6 +266,8 @@ def run_rank(a):
         sampling = vr.SAMPLE_TRILINEAR if a.sampling == "trilinear" else vr.SAMPLE_NEAREST
         views = [vr.benchmark_view(W, H, i) for i in range(8)]
         params = [split.apply(scene.frame_params(v, sampling)) for v in views]
+        # Brick copies are built by the first frame that reads them: the warm-up frames (one per view) do that, outside the timed
+        # region; `set_volume` in the JSON line reports what the upload / generation and every copy cost.
         # Rendering, the RCCL gather and the de-interleave copy are all ordered through ONE stream torch knows about: the
         # kernel is launched on it (the C ABI takes the raw hipStream_t), dist.gather() makes RCCL's stream wait for it, and
         # work.wait() makes it wait for RCCL before the buffer pair is rendered into again.
@@ -333,12 +352,13 @@ def run_rank(a):
         frame_check = check_frame()
 
     per_rank_kernel_ms = [tm.kernel_ms_sum / max(1, tm.launches)] if tm is not None else [0.0]
+    kernel_ms_max = float(tm.kernel_ms_max) if tm is not None else 0.0       # the longest single launch (Profiler.cpp:69-72 keeps sum and max)
     if distributed:
-        t = torch.tensor([elapsed, per_rank_kernel_ms[0]], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, per_rank_kernel_ms[0], kernel_ms_max], dtype=torch.float64, device=device)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                   # scaling is set by load balance — report every rank's kernel time
         per_rank_kernel_ms = [float(e[1]) for e in every]
-        elapsed, kernel_ms = max(float(e[0]) for e in every), max(per_rank_kernel_ms)
+        elapsed, kernel_ms, kernel_ms_max = max(float(e[0]) for e in every), max(per_rank_kernel_ms), max(float(e[2]) for e in every)
     else:
         kernel_ms = per_rank_kernel_ms[0]
 
@@ -349,7 +369,8 @@ def run_rank(a):
         partition = (f"{world} rank(s) x interleaved {band_rows}-row bands, "
                      f"{'gloo' if a.dry_run else 'RCCL'} gather to rank 0, 2 frames in flight") if distributed else "single GPU, whole frame"
         out = {
-            "metric": "Mrays/s (W*H / t_frame), 1024^3 volume @ 2048^2 viewport", "value": round(mrays, 2), "unit": "Mrays/s",
+            "metric": f"Mrays/s (W*H / t_frame), {n}^3 volume @ {W}x{H} viewport" if (n, W, H) != (1024, 2048, 2048) else
+                      "Mrays/s (W*H / t_frame), 1024^3 volume @ 2048^2 viewport", "value": round(mrays, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frame_check": frame_check,
@@ -362,26 +383,28 @@ def run_rank(a):
                                    "viewport": [W, H], "partition": partition}})
         else:
             mode_txt = {"nooptims": "ESL off, threshold 1.0", "default": "ESL on, threshold 0.95", "ertonly": "ESL off, threshold 0.95"}[a.mode]
-            out["config"] = {"workload": f"shell {n}^3 u8 (seed 1) @ {W}x{H}, reference's 8 benchmark views cycled, "
+            out["config"] = {"workload": f"BASELINE {a.config}: shell {n}^3 u{8 * bpv} (seed 1) @ {W}x{H}, reference's 8 benchmark views cycled, "
                                          f"mode={a.mode} ({mode_txt}, light_kd 0.6), sampling={a.sampling}",
-                             "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": 1, "ray_step": float(scene.params.ray_step),
+                             "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": bpv, "ray_step": float(scene.params.ray_step),
                              "partition": partition}
             # ALGORITHMIC bytes per launch: compulsory HBM traffic = every voxel once + the RGBA8 framebuffer,
             # 260 B/ray at 1024^3 @ 2048^2 in the full march; one launch covers 1/world of the frame and of the voxel rows.
             key = f"{a.mode}_{a.sampling}_{n}_{W}"
             if a.mode == "nooptims":
-                alg_bytes = (n ** 3 * 1 + 4 * W * H) / world
+                alg_bytes = (n ** 3 * bpv + 4 * W * H) / world
             else:
                 touched = recorded("tests/golden/vtouched.json", key)
                 alg_bytes = ((touched["mean_bytes"] if touched else n ** 3) + 4 * W * H) / world
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            traffic = recorded("profiles/r02_traffic.json", f"{key}_n{world}") or {}
+            traffic = recorded("profiles/r03_traffic.json", f"{key}_n{world}") or recorded("profiles/r02_traffic.json", f"{key}_n{world}") or {}
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic.get("bytes_per_launch"), "traffic_commit": traffic.get("commit"),
                 "traffic_kernel_ms": traffic.get("kernel_ms"),
-                "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "traffic_GBs": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9, 1) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
+                "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
                                          "(every other TRILINEAR view), 4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
@@ -406,11 +429,51 @@ def run_rank(a):
                     tv = r.timing()
                     per_view.append(round(tv.kernel_ms_sum / max(1, tv.launches), 4))
                 out["roofline"]["per_view_kernel_ms"] = per_view
-            if not a.no_extras and world == 1:
-                out["extras"] = extras(vr, r, scene, views, split, local[0], stream, render_stream, n, W, H)
+            if world == 1:
+                info = r.volume_info()
+                out["set_volume"] = {"upload_or_generate_ms": round(info.upload_ms, 3),
+                                     "copy_build_ms": {vr.COPY_NAMES[k]: round(info.build_ms[k], 3) for k in range(6) if (info.copies >> k) & 1},
+                                     "hbm_bytes": int(info.linear_bytes + info.bricked_bytes),
+                                     "note": "brick copies are built by the first frame that reads them (vr_hip_prepare builds them ahead of time): "
+                                             "what is listed is what this run's views and modes asked for so far"}
+            legs = set() if a.no_extras or world != 1 else set(x for x in a.extras.split(",") if x)
+            if legs:
+                out["extras"] = extras(vr, r, scene, views, split, local[0], stream, render_stream, n, W, H, bpv) if "modes" in legs else {}
                 set_mode(scene, a.mode)
-            if world == 1 and not a.no_cpu_baseline:
+                with torch.cuda.stream(render_stream):
+                    if "host" in legs:
+                        out["extras"]["host_buffer"] = bx.host_buffer_leg(vr, r, scene, views, sampling)
+                        out["host_buffer_ms"] = out["extras"]["host_buffer"]["ms_mean"]
+                    if a.simulate_ranks and "scale" in legs:
+                        out["scale_model"] = bx.scale_model(vr, dmod, r, scene, views, W, H, sampling, local[0], stream, render_stream.synchronize,
+                                                            ranks=tuple(int(x) for x in a.simulate_ranks.split(",")))
+                        set_mode(scene, a.mode)
+                # the other BASELINE configurations and the linear layout, each in a context of its own (this one keeps its copies)
+                others = {}
+                for name in ("c2", "c3", "c5", "c4"):
+                    if name == a.config or "configs" not in legs:
+                        continue
+                    free, _ = torch.cuda.mem_get_info(device)
+                    need = bx.CONFIGS[name][0] ** 3 * bx.CONFIGS[name][3] * 6
+                    if need > free * 0.8:
+                        others[name] = {"skipped": f"needs about {need >> 30} GiB of HBM, {free >> 30} GiB free"}
+                        continue
+                    others[name] = bx.run_config(vr, name, local_rank)
+                if others:
+                    out["extras"]["configs"] = others
+                lin = bx.run_config(vr, a.config, local_rank, layout=vr.LAYOUT_LINEAR, modes=("nooptims",), reps=2) if "linear" in legs else None
+                if lin:
+                    out["extras"]["linear_layout"] = {"kernel_ms": lin["nooptims"]["kernel_ms"], "per_view_kernel_ms": lin["nooptims"]["per_view_kernel_ms"],
+                                                  "roofline": lin["nooptims"]["roofline"], "hbm_bytes": lin["hbm_bytes"],
+                                                  "what": "the same workload with vr_hip_set_layout(VR_LAYOUT_LINEAR): the reference's x-fastest array, "
+                                                          "4 two-voxel loads per sample — north_star's literal layout, timed beside the product's brick copies"}
+                if "multi" in legs:
+                    out["extras"]["multi_overhead"] = bx.multi_overhead(vr, local_rank)
+            if world == 1 and not a.no_cpu_baseline and bpv == 1:
                 out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
+                # the comparison north_star asks for, labelled — vs_baseline itself stays null (BASELINE.md has no published number)
+                out["vs_cpu_baseline"] = {"ratio": round(mrays / out["cpu_baseline"]["value"], 1),
+                                          "what": f"value / cpu_baseline.value: this GPU line ({a.sampling}) against the reference's CPURenderer (NEAREST) on 1 host core"}
             else:
                 out["cpu_baseline"] = None
         sys.stdout.flush()
@@ -433,7 +496,7 @@ def set_mode(scene, mode):
         scene.set_modes(esl=True, ray_threshold=0.95)
 
 
-def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H):
+def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H, bpv=1):
     """Same volume and views in the other sampling mode and in the reference's two optimised configurations; for those the
     roofline uses V_touched, the bytes of the distinct 128-byte voxel lines the frame's sample set reads, counted by the
     CPU restatement in the build container (oracle/gen_vtouched.py -> tests/golden/vtouched.json)."""
@@ -445,8 +508,9 @@ def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H):
                               ("ertonly_nearest", "ertonly", vr.SAMPLE_NEAREST)):
         set_mode(scene, mode)
         ps = [split.apply(scene.frame_params(v, samp)) for v in views]
-        for p in ps:
-            r.render_volume_device(p, buf.data_ptr(), stream)
+        for _ in range(2):                          # builds the copies these views read; records / builds the measured-cost tile order
+            for p in ps:
+                r.render_volume_device(p, buf.data_ptr(), stream)
         render_stream.synchronize()
         r.timing_reset()
         t1 = time.perf_counter()
@@ -456,9 +520,10 @@ def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H):
         dt = (time.perf_counter() - t1) / 8
         tm = r.timing()
         kernel_ms = tm.kernel_ms_sum / max(1, tm.launches)
-        e = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_per_s": round(W * H / dt / 1e6, 1), "kernel_ms": round(kernel_ms, 4)}
+        e = {"ms_per_frame": round(dt * 1e3, 4), "Mrays_per_s": round(W * H / dt / 1e6, 1), "kernel_ms": round(kernel_ms, 4),
+             "kernel_ms_max": round(tm.kernel_ms_max, 4)}
         if mode == "nooptims":
-            alg = n ** 3 + 4 * W * H
+            alg = n ** 3 * bpv + 4 * W * H
         else:
             touched = recorded("tests/golden/vtouched.json", f"{mode}_{'trilinear' if samp == vr.SAMPLE_TRILINEAR else 'nearest'}_{n}_{W}")
             alg = (touched["mean_bytes"] + 4 * W * H) if touched else None

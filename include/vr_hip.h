@@ -107,6 +107,8 @@ typedef struct vr_timing {
 	                           (VolR.cpp:109-111, GPURenderer1.cu:107-110) */
 	uint64_t launches;      /* ray-march launches since the last vr_hip_timing_reset() */
 	double   kernel_ms_sum; /* sum of kernel_ms over those launches */
+	float    kernel_ms_max; /* the longest of those launches (the reference's Profiler keeps sum and max, Profiler.cpp:69-72) */
+	float    total_ms_max;  /* the longest vr_hip_render call (kernel + D2H) since the reset */
 } vr_timing;
 
 /* ---- lifetime: replaces GPURenderer1::GPURenderer1 / ~GPURenderer1 (GPURenderer1.cu:17-28) ---- */

@@ -1,0 +1,167 @@
+"""Legs of bench.py that are NOT the timed headline (rank 0, one GPU): the other BASELINE configurations, the linear layout, the
+reference's own timed region (host buffer, D2H included), the rank simulation behind `scale_model`, and the host overhead of the
+single-process several-device path.  Everything here goes through the product's C ABI; nothing touches oracle/."""
+import time
+
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+# BASELINE.json configs: name -> (cube edge, width, height, bytes per voxel)
+CONFIGS = {"c2": (256, 1024, 1024, 1), "c3": (512, 1920, 1080, 1), "c4": (1024, 2048, 2048, 1), "c5": (2048, 4096, 4096, 2)}
+
+
+def set_mode(scene, mode):
+    """The three configurations of the reference's optimisation benchmark, VolR.cpp:283-294."""
+    if mode == "nooptims":
+        scene.set_modes(esl=False, ray_threshold=1.0)
+    elif mode == "ertonly":
+        scene.set_modes(esl=False, ray_threshold=0.95)
+    else:
+        scene.set_modes(esl=True, ray_threshold=0.95)
+
+
+def time_views(r, params, buf, stream, sync, warm=2, reps=3):
+    """hipEvent kernel time of `reps` launches per parameter set after `warm` untimed ones (the first builds the brick copy the
+    view reads, the first two record / build the measured-cost tile order): per-view mean, overall mean and max."""
+    per_view, worst = [], 0.0
+    for p in params:
+        for _ in range(warm):
+            r.render_volume_device(p, buf.data_ptr(), stream)
+        sync()
+        r.timing_reset()
+        for _ in range(reps):
+            r.render_volume_device(p, buf.data_ptr(), stream)
+        sync()
+        t = r.timing()
+        per_view.append(t.kernel_ms_sum / max(1, t.launches))
+        worst = max(worst, t.kernel_ms_max)
+    return per_view, sum(per_view) / len(per_view), worst
+
+
+def roofline(alg_bytes, kernel_ms):
+    ach = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg_bytes), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5)}
+
+
+def run_config(vr, name, device_index=0, layout=None, modes=("nooptims", "default"), sampling=None, reps=3):
+    """One BASELINE configuration in a context of its own: shell volume generated in HBM, the reference's 8 benchmark views,
+    TRILINEAR; kernel ms (mean / max over the timed launches) per mode, and the full march's roofline over X*Y*Z*bpv + 4*W*H."""
+    n, W, H, bpv = CONFIGS[name]
+    r = vr.HipRenderer(device_index)
+    try:
+        if layout is not None:
+            r.set_layout(layout)
+        t0 = time.perf_counter()
+        r.generate_volume("shell", n, seed=1, bytes_per_voxel=bpv)
+        minmax = r.volume_minmax()[0]
+        scene = vr.Scene().set_volume(dims=(n, n, n), minmax=minmax)
+        r.set_transfer_fn(scene.tf, scene.esl)
+        samp = vr.SAMPLE_TRILINEAR if sampling is None else sampling
+        views = [vr.benchmark_view(W, H, i) for i in range(8)]
+        buf = torch.empty((H, W, 4), dtype=torch.uint8, device=f"cuda:{device_index}")
+        s = torch.cuda.Stream(torch.device("cuda", device_index))
+        out = {"volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": bpv, "ray_step": float(scene.params.ray_step)}
+        with torch.cuda.stream(s):
+            for mode in modes:
+                set_mode(scene, mode)
+                ps = [scene.frame_params(v, samp) for v in views]
+                per_view, mean, worst = time_views(r, ps, buf, s.cuda_stream, s.synchronize, reps=reps)
+                e = {"kernel_ms": round(mean, 4), "kernel_ms_max": round(worst, 4), "per_view_kernel_ms": [round(x, 4) for x in per_view],
+                     "Mrays_per_s": round(W * H / (mean * 1e-3) / 1e6, 1)}
+                if mode == "nooptims":
+                    e["roofline"] = roofline(n ** 3 * bpv + 4 * W * H, mean)
+                out[mode] = e
+        info = r.volume_info()
+        out["hbm_bytes"] = int(info.linear_bytes + info.bricked_bytes)
+        out["copies_built"] = [vr.COPY_NAMES[k] for k in range(6) if (info.copies >> k) & 1]
+        out["setup_s"] = round(time.perf_counter() - t0, 2)
+        return out
+    finally:
+        r.close()
+
+
+def host_buffer_leg(vr, r, scene, views, sampling):
+    """The reference's timed region (VolR.cpp:109-111 around GPURenderer1.cu:107-110): clear + kernel + copy-out into a HOST buffer,
+    through vr_hip_render; mean and max over the 8 views like Profiler.cpp:69-72.  PCIe-inclusive: never the headline value."""
+    W, H = views[0].width, views[0].height
+    r.set_window_buffer(W, H)
+    totals = []
+    for v in views:
+        p = scene.frame_params(v, sampling)
+        r.render_volume(p)                          # warm (copy / order already built by the timed region)
+        t0 = time.perf_counter()
+        r.render_volume(p)
+        totals.append((time.perf_counter() - t0) * 1e3)
+    return {"ms_mean": round(sum(totals) / len(totals), 4), "ms_max": round(max(totals), 4),
+            "what": "vr_hip_render: fused clear + kernel + D2H of W*H*4 bytes into pageable host memory, wall clock per call"}
+
+
+def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ranks=(2, 4, 8), modes=("nooptims", "default")):
+    """What ONE GPU can say about N: every rank's band set (the same interleaved bands the N-rank run uses) rendered alone, per
+    view; predicted efficiency = mean over views of t_1 / (N * max_r t_r) — load balance only, no gather, no host overhead."""
+    out = {"what": "each rank's bands rendered alone on this GPU (kernel ms, hipEvents); efficiency = mean_v t1(v) / (N * max_r t_r(v)); "
+                   "load balance only — the gather (16 MiB / N per rank over xGMI) and host overhead are not in it"}
+    for mode in modes:
+        set_mode(scene, mode)
+        whole = [vr.whole_frame(scene.frame_params(v, sampling)) for v in views]
+        t1, _, _ = time_views(r, whole, buf, stream, sync, reps=2)
+        res = {"t1_per_view_ms": [round(x, 4) for x in t1]}
+        for n in ranks:
+            band_rows = dmod.default_band_rows(H, n)
+            per_rank_view = []
+            for rank in range(n):
+                split = dmod.FrameSplit(W, H, n, rank, band_rows)
+                ps = [split.apply(scene.frame_params(v, sampling)) for v in views]
+                per_view, _, _ = time_views(r, ps, buf, stream, sync, reps=2)
+                per_rank_view.append(per_view)
+            per_rank = [sum(x) / len(x) for x in per_rank_view]
+            eff = [t1[v] / (n * max(per_rank_view[k][v] for k in range(n))) for v in range(len(views))]
+            res[f"n{n}"] = {"band_rows": band_rows, "per_rank_kernel_ms": [round(x, 4) for x in per_rank],
+                            "max_over_mean": round(max(per_rank) / (sum(per_rank) / n), 4),
+                            "predicted_efficiency": round(sum(eff) / len(eff), 4),
+                            "predicted_ms_per_frame": round(sum(max(per_rank_view[k][v] for k in range(n)) for v in range(len(views))) / len(views), 4)}
+        out[mode] = res
+    return out
+
+
+def multi_overhead(vr, device_index=0, n_volume=256, W=2048, H=2048, lists=(1, 2, 4, 8), frames=32):
+    """Host overhead of the single-process several-device path (vr_hip_multi_*) measured on ONE GPU: device lists that repeat
+    device 0.  Small volume (256^3: kernel time is a fraction of a millisecond), the headline viewport (the band copies and the
+    assemble kernel move the real 16 MiB): wall ms per frame, synchronous call against the two-frames-in-flight pipeline."""
+    out = {"what": f"vr_hip_multi_* with device lists [0]*N on one GPU, shell {n_volume}^3 @ {W}x{H}, full march TRILINEAR, view 1; wall ms per frame "
+                   f"over {frames} frames: synchronous calls / async pipeline (2 frames in flight); kernel_ms_sum = sum of the N band kernels of a frame"}
+    r0 = vr.HipRenderer(device_index)                       # the scene (TF, ESL, ray step) of this volume, by the feeders
+    try:
+        r0.generate_volume("shell", n_volume, seed=1)
+        scene = vr.Scene().set_volume(dims=(n_volume,) * 3, minmax=r0.volume_minmax()[0])
+    finally:
+        r0.close()
+    set_mode(scene, "nooptims")
+    p = scene.frame_params(vr.benchmark_view(W, H, 1), vr.SAMPLE_TRILINEAR)
+    for n in lists:
+        m = vr.MultiRenderer([device_index] * n)
+        try:
+            m.set_window_buffer(W, H)
+            m.generate_volume("shell", n_volume, seed=1)
+            m.set_transfer_fn(scene.tf, scene.esl)
+            bufs = [torch.empty((H, W, 4), dtype=torch.uint8, device=f"cuda:{device_index}") for _ in range(2)]
+            torch.cuda.synchronize()
+            for _ in range(3):
+                m.render_volume_device(p, bufs[0].data_ptr())
+            t0 = time.perf_counter()
+            for i in range(frames):
+                m.render_volume_device(p, bufs[i & 1].data_ptr())
+            sync_ms = (time.perf_counter() - t0) / frames * 1e3
+            per, _ = m.timing()
+            t0 = time.perf_counter()
+            for i in range(frames):
+                m.render_volume_device_async(p, bufs[i & 1].data_ptr())
+            m.sync()
+            async_ms = (time.perf_counter() - t0) / frames * 1e3
+            out[f"n{n}"] = {"transport": m.transport, "sync_ms_per_frame": round(sync_ms, 4), "pipelined_ms_per_frame": round(async_ms, 4),
+                            "kernel_ms_sum": round(sum(per), 4)}
+        finally:
+            m.close()
+    return out

@@ -54,7 +54,8 @@ class VrVolumeInfo(C.Structure):
 
 
 class VrTiming(C.Structure):
-    _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint64), ("kernel_ms_sum", C.c_double)]
+    _fields_ = [("kernel_ms", C.c_float), ("total_ms", C.c_float), ("launches", C.c_uint64), ("kernel_ms_sum", C.c_double),
+                ("kernel_ms_max", C.c_float), ("total_ms_max", C.c_float)]
 
 
 def library_path():

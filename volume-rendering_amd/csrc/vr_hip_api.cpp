@@ -71,7 +71,7 @@ struct vr_ctx {
 	// timing
 	EventPair ring[kEventRing]; int ring_head = 0;
 	hipEvent_t aux_start = nullptr, aux_stop = nullptr;
-	float last_kernel_ms = 0, last_total_ms = 0; uint64_t launches = 0; double kernel_ms_sum = 0;
+	float last_kernel_ms = 0, last_total_ms = 0; uint64_t launches = 0; double kernel_ms_sum = 0; float kernel_ms_max = 0, total_ms_max = 0;
 	std::string err;
 };
 
@@ -108,6 +108,7 @@ void harvest(vr_ctx *c, EventPair &p) {
 	float ms = 0;
 	if (hipEventSynchronize(p.stop) == hipSuccess && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
 		c->last_kernel_ms = ms; c->kernel_ms_sum += ms; c->launches++;
+		if (ms > c->kernel_ms_max) c->kernel_ms_max = ms;
 	}
 	p.pending = false;
 }
@@ -723,6 +724,7 @@ int vr_hip_render(vr_ctx *c, const vr_params *p, uint8_t *host_rgba) {
 	VR_TRY(c, hipStreamSynchronize(c->stream));
 	const auto t1 = std::chrono::steady_clock::now();
 	c->last_total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+	if (c->last_total_ms > c->total_ms_max) c->total_ms_max = c->last_total_ms;
 	return VR_OK;
 }
 
@@ -735,6 +737,8 @@ int vr_hip_timing(vr_ctx *c, vr_timing *out) {
 	out->total_ms = c->last_total_ms > 0 ? c->last_total_ms : c->last_kernel_ms;
 	out->launches = c->launches;
 	out->kernel_ms_sum = c->kernel_ms_sum;
+	out->kernel_ms_max = c->kernel_ms_max;
+	out->total_ms_max = c->total_ms_max;
 	return VR_OK;
 }
 
@@ -742,7 +746,7 @@ int vr_hip_timing_reset(vr_ctx *c) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	vr_timing t;
 	(void) vr_hip_timing(c, &t);
-	c->launches = 0; c->kernel_ms_sum = 0; c->last_kernel_ms = 0; c->last_total_ms = 0;
+	c->launches = 0; c->kernel_ms_sum = 0; c->last_kernel_ms = 0; c->last_total_ms = 0; c->kernel_ms_max = 0; c->total_ms_max = 0;
 	return VR_OK;
 }
 

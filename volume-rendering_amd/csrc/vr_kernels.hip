@@ -56,8 +56,7 @@ struct __attribute__((aligned(16))) LdsTables {
 //               that two workgroups per CU still reach the 32-wave limit next to 56 KiB of tables each
 //   kAddrWide : full 64-bit index arithmetic, no tables (anything larger; also the linear layout beyond 4 GiB)
 enum : int { kAddr32 = 0, kAddrLut64 = 1, kAddrWide = 2 };
-// s_getreg_b32 operand: register HW_REG_HW_ID (4), offset 0, 6 bits = wave_id[3:0] | simd_id[5:4]
-constexpr int kHwIdWaveSimd = ((6 - 1) << 11) | (0 << 6) | 4;
+
 
 // Brick address tables at FIXED LDS positions, so a lookup is one shift + one ds_read with an immediate offset:
 // z entries first ({offset(z), offset(min(z+1, Z-1))} pairs: one ds_read_b64 / b128 serves both slices), then x, then y.
@@ -454,15 +453,15 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	// tile_order: workgroup id -> tile number (measured-cost launch order), or NULL: identity.  tile_cost: per tile, the longest wave of
 	// the tile in 64-cycle units (atomicMax), or NULL: not recorded.  Both are consumed FIRST, before the tables are staged: the hot
 	// variants sit at the 80-SGPR limit of 8 waves per SIMD and their peak is the staging code, so nothing of the schedule may be live
-	// there or during the march — the wave's start time and the address of its tile's cost word wait in LDS for the end of the wave.
-	// The LDS slot of a wave is its hardware slot on the CU (HW_ID: SIMD id, wave id — unique among the resident waves of a CU, hence
-	// of a workgroup, and readable again at the end without keeping threadIdx or a lane mask alive).
-	__shared__ uint32_t wave_sched[64][4];
+	// there or during the march — the workgroup's start time and the address of its tile's cost word wait in LDS (one record per
+	// workgroup, written by thread 0 before the staging barrier) for the end of every wave.  (A per-wave record indexed by the wave's
+	// hardware slot, HW_ID, was tried and is WRONG: a wave that is context-switched out and back — several queues share the GPU —
+	// comes back in another slot, reads a record nobody wrote, and the atomic below goes to a wild address.)
+	__shared__ uint32_t group_sched[4];
 	const uint32_t tile_of_group = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
-	if ((threadIdx.x & 63u) == 0) {
+	if (threadIdx.x == 0) {
 		const uint64_t slot = tile_cost ? (uint64_t) (uintptr_t) (tile_cost + tile_of_group) : 0ull;
-		uint32_t *w = wave_sched[__builtin_amdgcn_s_getreg(kHwIdWaveSimd)];
-		w[0] = (uint32_t) (__builtin_readcyclecounter() >> 6); w[1] = (uint32_t) slot; w[2] = (uint32_t) (slot >> 32);
+		group_sched[0] = (uint32_t) (__builtin_readcyclecounter() >> 6); group_sched[1] = (uint32_t) slot; group_sched[2] = (uint32_t) (slot >> 32);
 	}
 	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
@@ -905,10 +904,11 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		       (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
 	}
 	*out_px = rgba;
-	// cost of the tile = its longest wave, in 64-cycle units (at least 1); written by the first lane that is still here
+	// cost of the tile = the end of its last wave after the start of the workgroup, in 64-cycle units (at least 1); every wave
+	// reports, through the first of its lanes that is still here
 	const uint32_t lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 	if (lane_id == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
-		const uint32_t *w = wave_sched[__builtin_amdgcn_s_getreg(kHwIdWaveSimd)];
+		const uint32_t *w = group_sched;
 		const uint64_t slot = ((uint64_t) w[2] << 32) | w[1];
 		if (slot != 0ull) atomicMax((uint32_t *) (uintptr_t) slot, ((uint32_t) (__builtin_readcyclecounter() >> 6) - w[0]) | 1u);
 	}
