@@ -83,3 +83,77 @@ def test_hot_kernels_keep_eight_waves_per_simd(vr):
     # quad bricks {NEAREST, TRILINEAR, Q8} x {u8, u16} x {32-bit, 64-bit z tables} = 12, voxel bricks (NEAREST) x 2 x 2 = 4,
     # run bricks {z, y} x {TRILINEAR, Q8} (u8, 32-bit) = 4
     assert found == 20, found
+
+
+def _disassemble_gfx950(lib_path, tmp_path):
+    """The gfx950 code objects embedded in the library, disassembled with the image's llvm-objdump: {symbol: [instruction lines]}."""
+    import glob
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    work = os.path.join(str(tmp_path), "lib.so")
+    shutil.copy(lib_path, work)
+    subprocess.check_call([objdump, "--offloading", work], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=str(tmp_path))
+    funcs, cur = {}, None
+    for bundle in sorted(glob.glob(work + ".*gfx950")):
+        text = subprocess.check_output([objdump, "-d", "--mcpu=gfx950", "--no-show-raw-insn", bundle], text=True, stderr=subprocess.DEVNULL)
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+            elif cur is not None and line.startswith("\t") or (cur is not None and re.match(r"^\s+[a-z_0-9]+", line)):
+                ins = line.split("//")[0].strip()
+                if ins:
+                    cur.append(ins)
+    return funcs
+
+
+def _vgprs(operand_text):
+    regs = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", operand_text):
+        if m.group(3) is not None:
+            regs.add(int(m.group(3)))
+        else:
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return regs
+
+
+def test_no_instruction_touches_a_gather_in_flight(vr, tmp_path):
+    """the software-pipelined march issues its gathers through inline asm and waits with hand-counted
+    `s_waitcnt vmcnt(N)`; that is only correct while the compiler never reads, copies or overwrites a destination register between
+    the load and the wait that covers it.  This walks the disassembly of the hot ray-march variants IN THE BUILT LIBRARY in program
+    order: every vector-memory load enters a queue with its destination registers, `s_waitcnt vmcnt(N)` retires all but the N
+    youngest, and no other instruction may name a register of a load still in the queue.  (Program order is exact inside the
+    straight-line loop body, where the risk is; across branches it is a conservative approximation of the hardware rule.)"""
+    funcs = _disassemble_gfx950(vr.library_path(), tmp_path)
+    checked = 0
+    for name, lines in funcs.items():
+        m = re.search(r"raymarch_kernelILi(\d)ELi1ELi0ELi(\d)E", name)
+        if not m or int(m.group(2)) not in (1, 2, 3, 4):
+            continue
+        checked += 1
+        inflight, loads, waits = [], 0, 0
+        for ins in lines:
+            parts = ins.split(None, 1)
+            op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
+            if op == "s_waitcnt":
+                w = re.search(r"vmcnt\((\d+)\)", rest)
+                if w:
+                    n = int(w.group(1))
+                    inflight = inflight[len(inflight) - n:] if n < len(inflight) else inflight
+                    if n == 0:
+                        inflight = []
+                    waits += 1
+                continue
+            regs = _vgprs(rest)
+            busy = set().union(*inflight) if inflight else set()
+            assert not (regs & busy), f"{name}: `{ins}` names v{sorted(regs & busy)} while a load into it is in flight"
+            if re.match(r"(global|flat|buffer|scratch)_load", op):
+                inflight.append(_vgprs(rest.split(",")[0]))
+                loads += 1
+            elif re.match(r"(global|flat|buffer|scratch)_(store|atomic)", op):
+                inflight.append(set())                      # shares the counter; has no destination to protect
+        assert loads >= 20 and waits >= 10, (name, loads, waits)
+    assert checked >= 8, checked
