@@ -102,7 +102,11 @@ def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ra
     """What ONE GPU can say about N: every rank's band set (the same interleaved bands the N-rank run uses) rendered alone, per
     view; predicted efficiency = mean over views of t_1 / (N * max_r t_r) — load balance only, no gather, no host overhead."""
     out = {"what": "each rank's bands rendered alone on this GPU (kernel ms, hipEvents); efficiency = mean_v t1(v) / (N * max_r t_r(v)); "
-                   "load balance only — the gather (16 MiB / N per rank over xGMI) and host overhead are not in it"}
+                   "load balance only — the gather (16 MiB / N per rank over xGMI) and host overhead are not in it.  pipelined_*: rank 0's bands of "
+                   "consecutive frames rendered CONCURRENTLY on two streams, as the N-rank run does (wall ms per frame over 32 frames): a rank's share "
+                   "of a frame fills the chip only briefly, two of them side by side keep it busy"}
+    two = [torch.cuda.Stream(), torch.cuda.Stream()]
+    buf2 = torch.empty_like(buf)
     for mode in modes:
         set_mode(scene, mode)
         whole = [vr.whole_frame(scene.frame_params(v, sampling)) for v in views]
@@ -118,7 +122,16 @@ def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ra
                 per_rank_view.append(per_view)
             per_rank = [sum(x) / len(x) for x in per_rank_view]
             eff = [t1[v] / (n * max(per_rank_view[k][v] for k in range(n))) for v in range(len(views))]
+            split0 = dmod.FrameSplit(W, H, n, 0, band_rows)
+            ps0 = [split0.apply(scene.frame_params(v, sampling)) for v in views]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(32):
+                r.render_volume_device(ps0[i % len(ps0)], (buf if i & 1 == 0 else buf2).data_ptr(), two[i & 1].cuda_stream)
+            torch.cuda.synchronize()
+            piped = (time.perf_counter() - t0) / 32 * 1e3
             res[f"n{n}"] = {"band_rows": band_rows, "per_rank_kernel_ms": [round(x, 4) for x in per_rank],
+                            "pipelined_ms_per_frame": round(piped, 4), "predicted_efficiency_pipelined": round(sum(t1) / len(t1) / (n * piped), 4),
                             "max_over_mean": round(max(per_rank) / (sum(per_rank) / n), 4),
                             "predicted_efficiency": round(sum(eff) / len(eff), 4),
                             "predicted_ms_per_frame": round(sum(max(per_rank_view[k][v] for k in range(n)) for v in range(len(views))) / len(views), 4)}

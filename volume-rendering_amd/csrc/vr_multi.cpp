@@ -9,8 +9,12 @@
 //     ncclCommInitAll; librccl is dlopen'ed so that single-GPU users never need it), or plain peer copies when RCCL is not
 //     available or the device list names one GPU twice (how the path is tested on a one-GPU box);
 //   * a copy kernel on device 0 de-interleaves the bands into the caller's frame;
-//   * TWO frames in flight (vr_hip_multi_render_device_async + vr_hip_multi_sync): band buffers, staging and timing events exist
-//     twice, frame i+1 is rendered while the bands of frame i travel and are assembled; nothing is created or destroyed per frame.
+//   * TWO frames in flight (vr_hip_multi_render_device_async + vr_hip_multi_sync): band buffers, staging, timing events AND STREAMS
+//     exist twice — from three devices on the two frames render concurrently, each slot on streams of its own: a device's share of a
+//     frame then fills the chip only briefly (at 8 devices: one load of waves marching in lockstep), and two such shares side by side
+//     keep it busy (measured with the band sets of an N-rank run on one GPU, bench.py scale_model: N = 4 0.87 -> 0.63 ms per frame,
+//     N = 8 0.58 -> 0.37; at N = 2 concurrency costs 8 %, so one and two devices keep one stream per device for both slots);
+//     frame i+1 also renders while the bands of frame i travel and are assembled; nothing is created or destroyed per frame.
 //     vr_hip_multi_render_device / vr_hip_multi_render are the synchronous calls the reference's interface needs (async + sync).
 // Built only on the public single-device ABI + the HIP runtime: nothing here touches vr_ctx internals.
 //
@@ -72,7 +76,7 @@ struct vr_multi {
 	int n = 0;
 	std::vector<int> dev;
 	std::vector<vr_ctx *> ctx;
-	std::vector<hipStream_t> stream;
+	std::vector<hipStream_t> streams[2];             // [slot][rank]: the two frames in flight run on streams of their own
 	// per frame slot
 	std::vector<hipEvent_t> rendered[kFrames];      // rank r's bands of the slot's frame are rendered (recorded on stream[r])
 	std::vector<void *> local[kFrames];             // rank r's bands on its own device (rank 0: its slice of staging[slot])
@@ -109,8 +113,9 @@ int fail(vr_multi *m, int code, const char *what, hipError_t e = hipSuccess) {
 // Kernels of the ranks launched so far may still be writing band buffers when a later step fails: never return to the caller
 // (who may free or reuse buffers) before every stream has drained.
 void quiesce(vr_multi *m) {
-	for (int r = 0; r < m->n; r++)
-		if (m->stream[r]) { (void) hipSetDevice(m->dev[r]); (void) hipStreamSynchronize(m->stream[r]); }
+	for (int s = 0; s < kFrames; s++)
+		for (int r = 0; r < m->n && r < (int) m->streams[s].size(); r++)
+			if (m->streams[s][r]) { (void) hipSetDevice(m->dev[r]); (void) hipStreamSynchronize(m->streams[s][r]); }
 	(void) hipGetLastError();
 	for (int s = 0; s < kFrames; s++) m->in_flight[s] = false;
 }
@@ -221,7 +226,8 @@ int vr_hip_multi_create(int n, const int *devices, vr_multi **out) {
 	*out = m;
 	m->n = n;
 	m->dev.assign(devices, devices + n);
-	m->ctx.assign(n, nullptr); m->stream.assign(n, nullptr);
+	m->ctx.assign(n, nullptr);
+	for (int s = 0; s < kFrames; s++) m->streams[s].assign(n, nullptr);
 	for (int s = 0; s < kFrames; s++) { m->rendered[s].assign(n, nullptr); m->local[s].assign(n, nullptr); }
 	m->distinct = true;
 	for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (devices[a] == devices[b]) m->distinct = false;
@@ -229,7 +235,9 @@ int vr_hip_multi_create(int n, const int *devices, vr_multi **out) {
 		int rc = vr_hip_create(devices[r], &m->ctx[r]);
 		if (rc != VR_OK) return fail(m, rc, m->ctx[r] ? vr_hip_last_error(m->ctx[r]) : "vr_hip_create failed");
 		VRM_TRY(m, hipSetDevice(devices[r]));
-		VRM_TRY(m, hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking));
+		VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[0][r], hipStreamNonBlocking));
+		if (n >= 3) VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[1][r], hipStreamNonBlocking));
+		else m->streams[1][r] = m->streams[0][r];             // one and two devices: both slots on one stream
 		for (int s = 0; s < kFrames; s++) VRM_TRY(m, hipEventCreateWithFlags(&m->rendered[s][r], hipEventDisableTiming));
 	}
 	VRM_TRY(m, hipSetDevice(devices[0]));
@@ -284,7 +292,8 @@ void vr_hip_multi_destroy(vr_multi *m) {
 	for (int r = 0; r < m->n; r++) {
 		(void) hipSetDevice(m->dev[r]);
 		for (int s = 0; s < kFrames; s++) if (m->rendered[s][r]) (void) hipEventDestroy(m->rendered[s][r]);
-		if (m->stream[r]) (void) hipStreamDestroy(m->stream[r]);
+		if (m->streams[1][r] && m->streams[1][r] != m->streams[0][r]) (void) hipStreamDestroy(m->streams[1][r]);
+		if (m->streams[0][r]) (void) hipStreamDestroy(m->streams[0][r]);
 		vr_hip_destroy(m->ctx[r]);
 	}
 	delete m;
@@ -367,8 +376,9 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 	const size_t slice = (size_t) m->local_rows * m->width * 4;
 	void *const *local = m->local[slot].data();
 	uint8_t *staging = (uint8_t *) m->staging[slot];
+	const hipStream_t *stream = m->streams[slot].data();     // this slot's stream on every device
 	VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
-	VRM_TRY_FRAME(m, hipEventRecord(m->t0[slot], m->stream[0]));
+	VRM_TRY_FRAME(m, hipEventRecord(m->t0[slot], stream[0]));
 	for (int r = 0; r < m->n; r++) {
 		vr_params pr = *p;
 		pr.x0 = 0; pr.out_width = m->width;
@@ -378,57 +388,57 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 		// peer-copy transport: device 0's stream read local[r] of frame i-2; this render must not overwrite it earlier.  (RCCL: the
 		// send ran on stream[r] itself.)  `retire` above already waited for that whole frame, so this wait is free — it keeps the
 		// ordering on the device even if the host-side wait is ever relaxed.
-		if (r > 0 && m->transport == kPeerCopy && m->frames >= (uint64_t) kFrames) VRM_TRY_FRAME(m, hipStreamWaitEvent(m->stream[r], m->gathered[slot], 0));
-		rc = forward(m, r, vr_hip_render_device(m->ctx[r], &pr, m->n == 1 ? dev_rgba : local[r], m->stream[r]));
+		if (r > 0 && m->transport == kPeerCopy && m->frames >= (uint64_t) kFrames) VRM_TRY_FRAME(m, hipStreamWaitEvent(stream[r], m->gathered[slot], 0));
+		rc = forward(m, r, vr_hip_render_device(m->ctx[r], &pr, m->n == 1 ? dev_rgba : local[r], stream[r]));
 		if (rc) { quiesce(m); return rc; }
-		VRM_TRY_FRAME(m, hipEventRecord(m->rendered[slot][r], m->stream[r]));
+		VRM_TRY_FRAME(m, hipEventRecord(m->rendered[slot][r], stream[r]));
 	}
 	if (m->n > 1) {
 		if (m->transport == kRccl) {
 			// one group: every other device sends its bands, device 0 receives them behind its own render
 			if (m->rccl.GroupStart() != ncclSuccess) { quiesce(m); return fail(m, VR_ERR_HIP, "ncclGroupStart failed"); }
 			for (int r = 1; r < m->n; r++) {
-				ncclResult_t a = m->rccl.Send(local[r], slice, ncclUint8, 0, m->comm[r], m->stream[r]);
-				ncclResult_t b = m->rccl.Recv(staging + slice * r, slice, ncclUint8, r, m->comm[0], m->stream[0]);
+				ncclResult_t a = m->rccl.Send(local[r], slice, ncclUint8, 0, m->comm[r], stream[r]);
+				ncclResult_t b = m->rccl.Recv(staging + slice * r, slice, ncclUint8, r, m->comm[0], stream[0]);
 				if (a != ncclSuccess || b != ncclSuccess) { (void) m->rccl.GroupEnd(); quiesce(m); return fail(m, VR_ERR_HIP, "ncclSend / ncclRecv failed"); }
 			}
 			if (m->rccl.GroupEnd() != ncclSuccess) { quiesce(m); return fail(m, VR_ERR_HIP, "ncclGroupEnd failed"); }
 		} else if (m->transport == kRcclSelf) {
 			// one communicator of size 1 on stream[0]: wait for every rank's render, then send-to-self / recv-from-self per band slice
 			VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
-			for (int r = 1; r < m->n; r++) VRM_TRY_FRAME(m, hipStreamWaitEvent(m->stream[0], m->rendered[slot][r], 0));
+			for (int r = 1; r < m->n; r++) VRM_TRY_FRAME(m, hipStreamWaitEvent(stream[0], m->rendered[slot][r], 0));
 			for (int r = 1; r < m->n; r++) {                   // one send / recv pair per group: pairs to the same peer match in order
 				if (m->rccl.GroupStart() != ncclSuccess) { quiesce(m); return fail(m, VR_ERR_HIP, "ncclGroupStart failed"); }
-				ncclResult_t a = m->rccl.Send(local[r], slice, ncclUint8, 0, m->comm[0], m->stream[0]);
-				ncclResult_t b = m->rccl.Recv(staging + slice * r, slice, ncclUint8, 0, m->comm[0], m->stream[0]);
+				ncclResult_t a = m->rccl.Send(local[r], slice, ncclUint8, 0, m->comm[0], stream[0]);
+				ncclResult_t b = m->rccl.Recv(staging + slice * r, slice, ncclUint8, 0, m->comm[0], stream[0]);
 				if (a != ncclSuccess || b != ncclSuccess) { (void) m->rccl.GroupEnd(); quiesce(m); return fail(m, VR_ERR_HIP, "ncclSend / ncclRecv (self) failed"); }
 				if (m->rccl.GroupEnd() != ncclSuccess) { quiesce(m); return fail(m, VR_ERR_HIP, "ncclGroupEnd failed"); }
 			}
 		} else {
 			VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
 			for (int r = 1; r < m->n; r++) {
-				VRM_TRY_FRAME(m, hipStreamWaitEvent(m->stream[0], m->rendered[slot][r], 0));
+				VRM_TRY_FRAME(m, hipStreamWaitEvent(stream[0], m->rendered[slot][r], 0));
 				if (m->dev[r] == m->dev[0])
-					VRM_TRY_FRAME(m, hipMemcpyAsync(staging + slice * r, local[r], slice, hipMemcpyDeviceToDevice, m->stream[0]));
+					VRM_TRY_FRAME(m, hipMemcpyAsync(staging + slice * r, local[r], slice, hipMemcpyDeviceToDevice, stream[0]));
 				else
-					VRM_TRY_FRAME(m, hipMemcpyPeerAsync(staging + slice * r, m->dev[0], local[r], m->dev[r], slice, m->stream[0]));
+					VRM_TRY_FRAME(m, hipMemcpyPeerAsync(staging + slice * r, m->dev[0], local[r], m->dev[r], slice, stream[0]));
 			}
-			VRM_TRY_FRAME(m, hipEventRecord(m->gathered[slot], m->stream[0]));
+			VRM_TRY_FRAME(m, hipEventRecord(m->gathered[slot], stream[0]));
 		}
 		VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
 		const size_t row_bytes = (size_t) m->width * 4;
 		if (row_bytes % 16 == 0 && ((uintptr_t) dev_rgba % 16) == 0) {
 			const uint32_t elems = (uint32_t) (row_bytes / 16);
-			hipLaunchKernelGGL(assemble_kernel<uint4>, dim3((elems + 255) / 256, m->height), dim3(256), 0, m->stream[0],
+			hipLaunchKernelGGL(assemble_kernel<uint4>, dim3((elems + 255) / 256, m->height), dim3(256), 0, stream[0],
 			                   (const uint4 *) staging, (uint4 *) dev_rgba, elems, m->height, (uint32_t) m->n, m->band_rows, m->local_rows);
 		} else {
-			hipLaunchKernelGGL(assemble_kernel<uint32_t>, dim3((m->width + 255) / 256, m->height), dim3(256), 0, m->stream[0],
+			hipLaunchKernelGGL(assemble_kernel<uint32_t>, dim3((m->width + 255) / 256, m->height), dim3(256), 0, stream[0],
 			                   (const uint32_t *) staging, (uint32_t *) dev_rgba, m->width, m->height, (uint32_t) m->n, m->band_rows, m->local_rows);
 		}
 		VRM_TRY_FRAME(m, hipGetLastError());
 	}
 	VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
-	VRM_TRY_FRAME(m, hipEventRecord(m->t1[slot], m->stream[0]));
+	VRM_TRY_FRAME(m, hipEventRecord(m->t1[slot], stream[0]));
 	if (consumer_stream) VRM_TRY_FRAME(m, hipStreamWaitEvent((hipStream_t) consumer_stream, m->t1[slot], 0));
 	m->in_flight[slot] = true;
 	m->frames++;
@@ -436,19 +446,19 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 		// First frame on this window: device 0 renders every other rank's bands itself and compares them with what arrived.
 		m->check_next = false;
 		VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
-		VRM_TRY_FRAME(m, hipMemsetAsync(m->check_count, 0, sizeof(uint32_t), m->stream[0]));
+		VRM_TRY_FRAME(m, hipMemsetAsync(m->check_count, 0, sizeof(uint32_t), stream[0]));
 		for (int r = 1; r < m->n; r++) {
 			vr_params pr = *p;
 			pr.x0 = 0; pr.out_width = m->width; pr.out_rows = m->local_rows; pr.band_rows = m->band_rows; pr.band_stride = (uint32_t) m->n; pr.band_first = (uint32_t) r;
-			rc = forward(m, 0, vr_hip_render_device(m->ctx[0], &pr, m->check, m->stream[0]));
+			rc = forward(m, 0, vr_hip_render_device(m->ctx[0], &pr, m->check, stream[0]));
 			if (rc) { quiesce(m); return rc; }
-			hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, m->stream[0], (const uint32_t *) m->check,
+			hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, stream[0], (const uint32_t *) m->check,
 			                   (const uint32_t *) (staging + slice * r), slice / 4, m->check_count);
 			VRM_TRY_FRAME(m, hipGetLastError());
 		}
 		uint32_t bad = 0;
-		VRM_TRY_FRAME(m, hipMemcpyAsync(&bad, m->check_count, sizeof bad, hipMemcpyDeviceToHost, m->stream[0]));
-		VRM_TRY_FRAME(m, hipStreamSynchronize(m->stream[0]));
+		VRM_TRY_FRAME(m, hipMemcpyAsync(&bad, m->check_count, sizeof bad, hipMemcpyDeviceToHost, stream[0]));
+		VRM_TRY_FRAME(m, hipStreamSynchronize(stream[0]));
 		if (bad != 0) {
 			quiesce(m);
 			char buf[256];
@@ -465,10 +475,11 @@ int vr_hip_multi_sync(vr_multi *m) {
 	if (m == nullptr) return VR_ERR_INVALID;
 	// oldest first, so that last_total_ms ends up as the newest frame's
 	for (int k = 0; k < kFrames; k++) { int rc = retire(m, (int) ((m->frames + (uint64_t) k) % kFrames)); if (rc) return rc; }
-	for (int r = m->n - 1; r >= 0; r--) {                    // sends on the other devices' streams have completed as well
-		VRM_TRY(m, hipSetDevice(m->dev[r]));
-		VRM_TRY(m, hipStreamSynchronize(m->stream[r]));
-	}
+	for (int s = 0; s < kFrames; s++)
+		for (int r = m->n - 1; r >= 0; r--) {                // sends on the other devices' streams have completed as well
+			VRM_TRY(m, hipSetDevice(m->dev[r]));
+			VRM_TRY(m, hipStreamSynchronize(m->streams[s][r]));
+		}
 	return VR_OK;
 }
 
