@@ -146,8 +146,9 @@ int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
  * 16-byte chunks of the brick order cover (volume-rendering_amd/csrc/vr_device.h): -1 = per view, the plane perpendicular to
  * the view's dominant axis (default); 0, 1, 2 = always that plane (where the copy exists: 1-byte voxels, edges up to 1024,
  * else (x,y)); 3 / 4 = the "run bricks", copies in which the two slices of a sample along z / along y are 8 adjacent bytes (one
- * gather per sample), which per-view selection uses for every view whose lane quads cannot be chunk-aligned.  Speed only; testing and tuning
- * aid.  No reference counterpart. */
+ * gather per sample), which per-view selection uses for every view whose lane quads cannot be chunk-aligned; 5 = 2-byte volumes read
+ * their oct bricks (one 16-byte element per cell) for EVERY view — per-view selection uses them for orthogonal views with at most
+ * one cell per pixel and the quad bricks otherwise.  Speed only; testing and tuning aid.  No reference counterpart. */
 int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
 /* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
@@ -239,7 +240,8 @@ uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
  * 1024^3, the context's stream, synchronous) by the first frame that wants it, so a NEAREST-only session holds the linear array
  * + the voxel bricks and nothing else.  vr_hip_prepare builds the copies named by `copies` (VR_COPY_* bits) now — what a
  * benchmark, or a caller about to vr_hip_release_linear_copy, does.  Copies the layout policy does not have at this volume
- * size (the second / third quad plane and the run bricks need 1-byte voxels and edges <= 1024; voxel bricks edges <= 2048) are
+ * size (the second / third quad plane and the run bricks need 1-byte voxels and edges <= 1024; voxel bricks edges <= 2048; oct
+ * bricks 2-byte voxels) are
  * skipped silently; every copy but the first quad copy is refused (VR_ERR_ALLOC) unless half of the HBM stays free — frames then
  * read the next best copy, see vr_volume_info::copies_refused.  No reference counterpart (GPURenderer4 builds its one cudaArray
  * in set_volume, GPURenderer4.cu:123-141). */
@@ -249,8 +251,10 @@ uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
 #define VR_COPY_RUN_Z    (1u << 3)   /* run bricks along z: TRILINEAR views that cannot be chunk-aligned, marching mostly along x or y */
 #define VR_COPY_RUN_Y    (1u << 4)   /* run bricks along y: the same, marching mostly along z */
 #define VR_COPY_VOXEL    (1u << 5)   /* voxel bricks: NEAREST */
-#define VR_COPY_ALL      0x3fu
-#define VR_COPY_KINDS    6
+#define VR_COPY_OCT      (1u << 6)   /* oct bricks (2-byte voxels only): one 16-byte element per cell = the whole 2x2x2 neighbourhood; what
+                                        TRILINEAR reads for 2-byte voxels — one gather per sample instead of the quad bricks' two */
+#define VR_COPY_ALL      0x7fu
+#define VR_COPY_KINDS    7
 int vr_hip_prepare(vr_ctx *ctx, uint32_t copies);
 
 /* ---- what the resident volume occupies in HBM, and giving some of it back ----

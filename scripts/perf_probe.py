@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--layout", default="bricked")
     ap.add_argument("--bpv", type=int, default=1, help="bytes per voxel of the generated volume")
     ap.add_argument("--tile-map", default="", help="lane_map,phase_x,phase_y (default: automatic)")
-    ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz, 3 / 4 run bricks along z / y")
+    ap.add_argument("--plane", type=int, default=-1, help="brick chunk plane: -1 per view, 0 xy, 1 xz, 2 yz, 3 / 4 run bricks along z / y, 5 oct bricks for every view (2-byte voxels)")
     ap.add_argument("--each", action="store_true", help="synchronise after every launch and list the kernel time of each")
     ap.add_argument("--sched", type=int, default=1, help="vr_hip_set_tile_scheduling: 0 workgroup order, 1 measured-cost order")
     ap.add_argument("--wide", type=int, default=0, help="vr_hip_set_wide_addressing value (2: 64-bit z tables, 1024-thread workgroups)")

@@ -32,9 +32,9 @@ def test_struct_layout_matches_header(vr):
     assert C.sizeof(vr.VrTiming) == 32 and vr.VrTiming.kernel_ms_max.offset == 24
     from importlib import import_module
     info = import_module("volume-rendering_amd.binding").VrVolumeInfo
-    # 10 u32 + 2 u64 + 3 u32 + 6 floats + 1 float = 40 + 16 + 12 + 28 = 96 bytes, u64 fields 8-aligned at 40
-    assert info.linear_bytes.offset == 40 and info.copies.offset == 56 and info.build_ms.offset == 68 and info.upload_ms.offset == 92
-    assert C.sizeof(info) == 96
+    # 10 u32 + 2 u64 + 3 u32 + 7 floats + 1 float = 40 + 16 + 12 + 32 = 100 bytes -> 104 (u64 fields 8-aligned at 40)
+    assert info.linear_bytes.offset == 40 and info.copies.offset == 56 and info.build_ms.offset == 68 and info.upload_ms.offset == 96
+    assert C.sizeof(info) == 104
 
 
 def test_no_cpu_fallback(vr):
@@ -77,12 +77,12 @@ def test_hot_kernels_keep_eight_waves_per_simd(vr):
         sampling, bpv, addr, layout = (int(m.group(i)) for i in (2, 3, 4, 5))
         sgprs, vgprs, scratch = int(m.group(6)), int(m.group(7)), int(m.group(8))
         assert scratch == 0, (m.group(1), "spills to scratch")
-        if layout in (1, 2, 3, 4) and addr in (0, 1):           # quad bricks, run bricks (z / y), voxel bricks
+        if layout in (1, 2, 3, 4, 5) and addr in (0, 1):        # quad bricks, run bricks (z / y), voxel bricks, oct bricks
             found += 1
             assert sgprs <= 80 and vgprs <= 64, (m.group(1), sgprs, vgprs)
     # quad bricks {NEAREST, TRILINEAR, Q8} x {u8, u16} x {32-bit, 64-bit z tables} = 12, voxel bricks (NEAREST) x 2 x 2 = 4,
-    # run bricks {z, y} x {TRILINEAR, Q8} (u8, 32-bit) = 4
-    assert found == 20, found
+    # run bricks {z, y} x {TRILINEAR, Q8} (u8, 32-bit) = 4, oct bricks {TRILINEAR, Q8} (u16) x {32-bit, 64-bit z tables} = 4
+    assert found == 24, found
 
 
 def _disassemble_gfx950(lib_path, tmp_path):

@@ -167,6 +167,25 @@ def test_u16_volume_matches_oracle(vr, gpu, golden, oracle):
             out = gpu.render_volume(p)
             ref = oracle.render(p, vox16, st["tf"], st["esl"])
             assert compare_frames(out, ref) == (0, 0), (label, mode)
+    # orthogonal TRILINEAR views read the oct bricks (one 16-byte element per cell), perspective ones the quad bricks, NEAREST the voxel bricks
+    info = gpu.volume_info()
+    assert info.copies == vr.COPY_OCT | vr.COPY_QUAD_XY | vr.COPY_VOXEL and info.bricked_bytes == (16 + 8 + 2) * 32 ** 3, (info.copies, info.bricked_bytes)
+    # the three layouts a 2-byte TRILINEAR frame can read agree: oct bricks (forced for every view), quad bricks (forced plane), the linear array
+    for label in ("bench64_view1_default", "bench64_view6_default"):
+        case = [c for c in golden.cases(True) if c["label"] == label][0]
+        for mode in (vr.SAMPLE_TRILINEAR, vr.SAMPLE_TRILINEAR_Q8):
+            p = golden.params(case, mode)
+            gpu.set_brick_plane(5)
+            oct_frame = gpu.render_volume(p)
+            gpu.set_brick_plane(0)
+            quad_frame = gpu.render_volume(p)
+            gpu.set_brick_plane(-1)
+            assert np.array_equal(gpu.render_volume(p), oct_frame)
+            gpu.set_layout(vr.LAYOUT_LINEAR)
+            linear_frame = gpu.render_volume(p)
+            gpu.set_layout(vr.LAYOUT_BRICKED)
+            assert np.array_equal(oct_frame, quad_frame) and np.array_equal(oct_frame, linear_frame), (label, mode)
+            assert np.array_equal(oct_frame, oracle.render(p, vox16, st["tf"], st["esl"])), (label, mode)
     # u8 * 257 in NEAREST mode is the same picture as the u8 volume except for the /65535 vs /255 shading scale
     case = [c for c in golden.cases(True) if c["label"] == "nolight_view1"][0]
     out16 = gpu.render_volume(golden.params(case, vr.SAMPLE_NEAREST))
@@ -425,7 +444,7 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         info = r.volume_info()
         assert (info.dim_x, info.dim_y, info.dim_z, info.bytes_per_voxel) == (32, 32, 32, 1)
         # nothing but the linear array after set_volume; the policy has all six copies at this size
-        assert info.layout == vr.LAYOUT_BRICKED and info.copies == 0 and info.bricked_bytes == 0 and info.copies_in_policy == vr.COPY_ALL
+        assert info.layout == vr.LAYOUT_BRICKED and info.copies == 0 and info.bricked_bytes == 0 and info.copies_in_policy == vr.COPY_ALL & ~vr.COPY_OCT
         assert info.brick_copies == 0 and info.brick_copies_wanted == 3 and info.linear_resident == 1 and info.linear_bytes >= 32 ** 3
         with pytest.raises(vr.VrError) as e:
             r.release_linear_copy()                                            # no brick copy resident yet
@@ -441,9 +460,9 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         assert info.copies in (vr.COPY_VOXEL | vr.COPY_RUN_Z, vr.COPY_VOXEL | vr.COPY_RUN_Y) and info.brick_copies == 0
         r.prepare()                                                            # everything the policy has
         info = r.volume_info()
-        assert info.copies == vr.COPY_ALL and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7 and info.run_copy == 7
+        assert info.copies == vr.COPY_ALL & ~vr.COPY_OCT and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7 and info.run_copy == 7
         assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3
-        assert all(ms > 0 for ms in info.build_ms) and info.copies_refused == 0 and info.upload_ms > 0
+        assert all(ms > 0 for ms in list(info.build_ms)[:6]) and info.build_ms[6] == 0 and info.copies_refused == 0 and info.upload_ms > 0
         before = [near, tri]
         r.release_linear_copy()
         info = r.volume_info()

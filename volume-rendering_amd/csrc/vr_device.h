@@ -18,7 +18,7 @@ constexpr uint32_t kMaxRaySteps = 1u << 22;
 // up to kDepth speculative fetches beyond its exit point, which the kLutPad repeated edge entries of the address tables absorb:
 // the host checks kOverrunSteps * (cells per step) + 1.5 <= kLutPad per frame and otherwise runs the coordinate-clamping variant.
 #ifndef VR_DEPTH
-#define VR_DEPTH 4
+#define VR_DEPTH 5
 #endif
 constexpr int kDepth = VR_DEPTH, kSlots = kDepth + 1;
 // Lazy exit test (unclamped march): whether a lane has left its ray segment is tested once per rotation of the fetch slots (and by
@@ -30,6 +30,7 @@ constexpr int kDepth = VR_DEPTH, kSlots = kDepth + 1;
 #ifndef VR_RUN_DEPTH
 #define VR_RUN_DEPTH VR_DEPTH
 #endif
+constexpr int kDepthTwoByte = 3;        // TRILINEAR with 2-byte voxels: four registers per slot — three samples ahead keep 64 VGPRs
 constexpr int kRunDepth = VR_RUN_DEPTH, kMaxDepth = kRunDepth > kDepth ? kRunDepth : kDepth;
 constexpr int kOverrunSteps = kMaxDepth + (VR_LAZY_EXIT ? kMaxDepth + 1 : 0);     // steps a speculative fetch may lie beyond a ray's exit point
 constexpr int kLutPad = (kOverrunSteps * 5 + 2) / 3 + 2;                          // >= kOverrunSteps * 1.666 (the reference's longest step, in cells) + 1.5
@@ -97,7 +98,13 @@ struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr;
 //                   chunk cover 2x2 cells.  With 1-byte elements a chunk covers 4x4 cells of a slice and a 128-byte line 8x8x2
 //                   voxels: the lane quads of views that are not aligned stay inside one chunk far more often, and the
 //                   compulsory traffic of a frame is the volume itself (1 GiB at 1024^3).
-enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4 };
+//   kLayoutOct    : "oct bricks" for TRILINEAR sampling of 2-BYTE voxels — element (x,y,z) is the whole 2x2x2 neighbourhood, eight
+//                   2-byte voxels = ONE aligned 16-byte word, in the brick order of the 2-byte quad copy.  Measured
+//                   (scripts/ubench/tcp_gather64.hip, column "u16 oct"): an aligned 16-byte gather costs what ONE 8-byte gather costs
+//                   (6.7-10 ns per wave in every lane pattern), and the quad bricks need two of those per sample.  Twice the bytes of
+//                   the quad copy (16 per voxel: 128 GiB for 2048^3); for 1-byte voxels the same idea (8-byte octets) lost against
+//                   the run bricks, which share their elements along z.
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5 };
 __host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY; }
 __host__ __device__ constexpr bool is_brick_table_layout(int layout) { return layout == (int) kLayoutBricked || layout == (int) kLayoutVoxel; }
 constexpr uint32_t kRunLen = 9, kRunBytes = kRunLen * 4, kRunBrickBytes = 64 * kRunBytes;       // 8x8 cell columns per brick
@@ -122,7 +129,7 @@ constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
 // the brick copies a context may hold (bit i of vr_hip_prepare's mask / vr_volume_info::copies = copy i): quad bricks per chunk
 // plane, run bricks along z / y, voxel bricks
-enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyKinds = 6 };
+enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyOct = 6, kCopyKinds = 7 };
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
 	constexpr uint8_t table[4][9] = {
@@ -152,6 +159,8 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bytes_per
 // linear -> voxel bricks (NEAREST): element (x,y,z) = the voxel, brick order of the (x,y) quad copy
 hipError_t launch_brickify_voxel(const void *linear, void *voxel_bricks, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                                  hipStream_t stream);
+// linear -> oct bricks (2-byte voxels): element = the 2x2x2 neighbourhood, 16 bytes
+hipError_t launch_brickify_oct(const void *linear, void *oct_bricks, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 // linear -> run bricks (1-byte voxels)
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout /* kLayoutRun | kLayoutRunY */, uint32_t dim_x, uint32_t dim_y,
                                uint32_t dim_z, hipStream_t stream);

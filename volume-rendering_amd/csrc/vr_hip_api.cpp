@@ -42,11 +42,11 @@ struct vr_ctx {
 	// Brick copies of the resident volume (vr_device.h), built ON FIRST USE by the frame that wants them (or ahead of time by
 	// vr_hip_prepare): a NEAREST-only session never pays for the quad / run copies, a session that only looks along z never
 	// builds the (x,z) / (y,z) planes.  copy[kCopyQuadXY..YZ] = quad bricks per chunk plane, kCopyRunZ / kCopyRunY = run bricks,
-	// kCopyVoxel = voxel bricks (what NEAREST reads).  copy_failed: a build was refused (HBM guard / allocation) — not retried
+	// kCopyVoxel = voxel bricks (what NEAREST reads), kCopyOct = oct bricks (what TRILINEAR reads for 2-byte voxels).  copy_failed: a build was refused (HBM guard / allocation) — not retried
 	// until the next set_volume, so a frame never stalls twice on the same refusal.
-	void *copy[kCopyKinds] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-	float copy_build_ms[kCopyKinds] = { 0, 0, 0, 0, 0, 0 };
-	bool copy_failed[kCopyKinds] = { false, false, false, false, false, false };
+	void *copy[kCopyKinds] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	float copy_build_ms[kCopyKinds] = { 0, 0, 0, 0, 0, 0, 0 };
+	bool copy_failed[kCopyKinds] = { false, false, false, false, false, false, false };
 	float upload_ms = 0;                    // host -> HBM copy (or generation) of the linear array in the last set_volume
 	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
 	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
@@ -66,6 +66,7 @@ struct vr_ctx {
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
 	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order
+	bool oct_always = false;                // vr_hip_set_brick_plane(5): 2-byte voxels read the oct bricks for every view (testing)
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
 	// timing
@@ -331,6 +332,20 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// NEAREST: the voxel bricks (one voxel per element) unless a quad copy is forced (testing) or a 64-bit path is
 	if (p->sampling == VR_SAMPLE_NEAREST && bricked && copy_possible(c, kCopyVoxel) && c->brick_plane_force < 0 && c->force_wide != 1)
 		a.layout = kLayoutVoxel;
+	// TRILINEAR with 2-byte voxels: the oct bricks (one 16-byte gather per sample instead of two 8-byte ones) for ORTHOGONAL views
+	// with at most one cell per pixel — there the pixels of a lane quad share their elements and the halved gather count wins
+	// (1024^3: 4.0 / 5.8 / 4.0 / 4.2 ms against 5.1 / 6.0 / 5.9 / 5.6 with the quad bricks; 2048^3: 28-44 against 40-48 ms); the
+	// rays of a perspective view diverge to more than a cell per pixel, every lane then pulls 16 bytes it uses once, and the doubled
+	// traffic loses (4.2-5.5 against 3.5-4.4 ms): those keep the quad bricks.  Not when a quad copy is forced (testing) or the
+	// index-arithmetic path is.
+	if (p->sampling != VR_SAMPLE_NEAREST && c->bpv == 2 && bricked && copy_possible(c, kCopyOct) && c->brick_plane_force < 0 && c->force_wide != 1 &&
+	    (!p->view.perspective || c->oct_always)) {
+		bool dense = true;
+		const float half[3] = { a.half_x, a.half_y, a.half_z };
+		for (int ax = 0; ax < 3; ax++)
+			if ((std::fabs(p->view.right_plane[ax]) + std::fabs(p->view.up_plane[ax])) * half[ax] > 1.0f) dense = false;
+		if (dense || c->oct_always) a.layout = kLayoutOct;
+	}
 	a.nbx = (c->dim[0] + kBrickEdge - 1) / kBrickEdge; a.nby = (c->dim[1] + kBrickEdge - 1) / kBrickEdge;
 	a.nbz = (c->dim[2] + kBrickEdge - 1) / kBrickEdge;
 	{   // RaycasterBase.h:59-63: index / esl_block_dims, prepared as shift or multiply-high
@@ -364,7 +379,8 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// released) degrades to the next best resident copy; the image is the same.
 	const void *brick_copy = nullptr;
 	if (a.layout != kLayoutLinear) {
-		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel : kCopyQuadXY + a.brick_plane;
+		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
+		                      a.layout == kLayoutOct ? kCopyOct : kCopyQuadXY + a.brick_plane;
 		brick_copy = copy_for(c, want);
 		if (brick_copy == nullptr && want != kCopyQuadXY) {
 			a.layout = kLayoutBricked; a.brick_plane = kPlaneXY;
@@ -375,6 +391,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			if (p->sampling == VR_SAMPLE_NEAREST && c->copy[kCopyVoxel] && c->force_wide != 1) { a.layout = kLayoutVoxel; brick_copy = c->copy[kCopyVoxel]; }
 			else if (p->sampling != VR_SAMPLE_NEAREST && !c->force_wide && c->copy[kCopyRunZ]) { a.layout = kLayoutRun; brick_copy = c->copy[kCopyRunZ]; }
 			else if (p->sampling != VR_SAMPLE_NEAREST && !c->force_wide && c->copy[kCopyRunY]) { a.layout = kLayoutRunY; brick_copy = c->copy[kCopyRunY]; }
+			else if (p->sampling != VR_SAMPLE_NEAREST && c->bpv == 2 && c->force_wide != 1 && c->copy[kCopyOct]) { a.layout = kLayoutOct; brick_copy = c->copy[kCopyOct]; }
 			else a.layout = kLayoutLinear;
 		}
 	}
@@ -459,6 +476,7 @@ uint32_t max_dim_of(const vr_ctx *c) { return std::max(c->dim[0], std::max(c->di
 uint64_t copy_bytes(const vr_ctx *c, uint32_t kind) {
 	if (kind <= kCopyQuadYZ) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
 	if (kind == kCopyVoxel) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
+	if (kind == kCopyOct) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 8 * c->bpv;
 	return run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
 }
 
@@ -468,6 +486,7 @@ bool copy_in_policy(const vr_ctx *c, uint32_t kind) {
 	if (c->layout != VR_LAYOUT_BRICKED || c->dim[0] == 0) return false;
 	if (kind == kCopyQuadXY) return true;
 	if (kind == kCopyVoxel) return max_dim_of(c) <= 2048u;
+	if (kind == kCopyOct) return c->bpv == 2 && max_dim_of(c) <= 2048u;
 	if (kind == kCopyQuadXZ || kind == kCopyQuadYZ) return c->bpv == 1 && max_dim_of(c) <= 1024u && copy_bytes(c, kind) <= (1ull << 32);
 	return c->bpv == 1 && max_dim_of(c) <= 1024u;
 }
@@ -484,7 +503,9 @@ int build_copy(vr_ctx *c, uint32_t kind) {
 	if (c->copy[kind]) return VR_OK;
 	if (!copy_possible(c, kind)) return VR_ERR_NOT_READY;
 	const uint64_t bytes = copy_bytes(c, kind);
-	if (kind != kCopyQuadXY) {
+	// the half-of-the-HBM rule exempts the ONE copy a sampling mode cannot do without: the first quad copy — for 2-byte voxels the oct
+	// copy, which TRILINEAR reads instead (building both is left to a caller who forces the quad copy: testing)
+	if (kind != kCopyQuadXY && !(kind == kCopyOct && c->copy[kCopyQuadXY] == nullptr)) {
 		size_t free_b = 0, total_b = 0;
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) { (void) hipGetLastError(); c->copy_failed[kind] = true; return VR_ERR_ALLOC; }
 	}
@@ -494,6 +515,7 @@ int build_copy(vr_ctx *c, uint32_t kind) {
 	if (e == hipSuccess) {
 		if (kind <= kCopyQuadYZ) e = launch_brickify(c->vol, dst, c->bpv, kind - kCopyQuadXY, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else if (kind == kCopyVoxel) e = launch_brickify_voxel(c->vol, dst, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else if (kind == kCopyOct) e = launch_brickify_oct(c->vol, dst, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else e = launch_brickify_run(c->vol, dst, kind == kCopyRunY ? kLayoutRunY : kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream);
 	}
 	if (e == hipSuccess) e = hipEventRecord(c->aux_stop, c->stream);
@@ -673,8 +695,9 @@ int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 
 int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	if (plane < -1 || plane > (int32_t) kPlanes + 1) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z) or 4 (run bricks along y)");
-	c->brick_plane_force = plane;
+	if (plane < -1 || plane > (int32_t) kPlanes + 2) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z), 4 (run bricks along y) or 5 (oct bricks for every view of a 2-byte volume)");
+	c->oct_always = plane == (int32_t) kPlanes + 2;
+	c->brick_plane_force = c->oct_always ? -1 : plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane
 	return VR_OK;
 }

@@ -92,10 +92,14 @@ __device__ __forceinline__ void managed_load8(uint32_t &dst, uint32_t byte_offse
 }
 // TRILINEAR with 2-byte voxels: the two 8-byte elements of a quad-brick sample, by 64-bit address (copies beyond 4 GiB included)
 template <int BPV, int ADDR, int LAYOUT> struct ManagedTri {
-	static constexpr bool value = Managed<BPV, ADDR, LAYOUT>::value || (BPV == 2 && LAYOUT == kLayoutBricked && (ADDR == kAddr32 || ADDR == kAddrLut64));
+	static constexpr bool value = Managed<BPV, ADDR, LAYOUT>::value || (BPV == 2 && (LAYOUT == kLayoutBricked || LAYOUT == kLayoutOct) && (ADDR == kAddr32 || ADDR == kAddrLut64));
 };
 __device__ __forceinline__ void managed_load64(uint64_t &dst, uint64_t address) {      // split into halves only AFTER the wait
 	asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(address));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void managed_load128(u32x4 &dst, uint64_t address) {        // oct bricks: the 2x2x2 neighbourhood of 2-byte voxels
+	asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(address));
 }
 
 // Single voxel (NEAREST).  LINEAR: the reference's array.  BRICKED: component 0 of the quad element (x,y,z) IS v(x,y,z), so
@@ -189,6 +193,7 @@ template <int BPV, int LAYOUT> struct TriFetch {
 	uint32_t w0, w1, w2, w3;
 	uint64_t q;                                      // run bricks, managed load: both slices as ONE 64-bit destination (w0 = low, w1 = high)
 	uint64_t q2;                                     // 2-byte voxels, managed loads: q = the element of slice z (w0, w1), q2 = of slice z+1 (w2, w3)
+	u32x4 o;                                         // oct bricks, managed load: the whole 16-byte element (w0 .. w3)
 };
 
 // `clamp` (wave-uniform) = false is allowed for positions INSIDE the volume's cube, i.e. coordinates in (-1, N): there
@@ -199,7 +204,7 @@ template <int BPV, int ADDR, int LAYOUT, bool MANAGED = false>
 __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, const RayKernelArgs &a, const uint32_t *lut,
                                                            float xb, float yb, float zb, bool clamp) {
 	TriFetch<BPV, LAYOUT> f;
-	f.q = 0; f.q2 = 0;
+	f.q = 0; f.q2 = 0; f.o = (u32x4) (0u);
 	if (clamp) {
 		xb = __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x);
 		yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
@@ -222,6 +227,15 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 			const uint2 both = *(const uint2 *) address;                                     // global_load_dwordx2, 4-byte aligned
 			f.w0 = both.x; f.w1 = both.y;
 		}
+	} else if (LAYOUT == kLayoutOct) {
+		// oct bricks (2-byte voxels): ONE aligned 16-byte element holds both slices; tables as for the quad bricks (the z + 1 entry is unused)
+		typedef LutCfg<ADDR> L;
+		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
+		uint64_t address;
+		if (ADDR == kAddr32) address = (uint64_t) (uintptr_t) vol + (uint64_t) (exy + lut[(int) L::z_words * (iz + kLutPad)]);
+		else { const uint2 zz = *(const uint2 *) (lut + (int) L::z_words * (iz + kLutPad)); address = (uint64_t) (uintptr_t) vol + ((((uint64_t) zz.y) << 32 | zz.x) + exy); }
+		if (MANAGED && ManagedTri<BPV, ADDR, LAYOUT>::value) managed_load128(f.o, address);
+		else { const uint4 v = *(const uint4 *) address; f.w0 = v.x; f.w1 = v.y; f.w2 = v.z; f.w3 = v.w; }
 	} else if (LAYOUT == kLayoutBricked) {
 		constexpr uint32_t kElem = 4 * BPV;
 		const uint8_t *q0, *q1;
@@ -438,6 +452,7 @@ __device__ __forceinline__ void pin(uint32_t &x, uint32_t &y) { asm volatile("" 
 __device__ __forceinline__ void pin(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) { asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w)); }
 __device__ __forceinline__ void pin(uint64_t &x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(uint64_t &x, uint64_t &y) { asm volatile("" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void pin(u32x4 &x) { asm volatile("" : "+v"(x)); }
 template <int I> __device__ __forceinline__ void managed_wait() {       // s_waitcnt vmcnt(I): all but the I youngest gathers have landed
 	static_assert(I >= 0 && I <= 63, "vmcnt is a 6-bit field on gfx9");
 	asm volatile("s_waitcnt vmcnt(%0)" : : "n"(I));
@@ -493,7 +508,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			for (uint32_t j = t; j < no + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, no); lut[L::y_at + j] = (i >> 3) * a.nbx * kRunBrickBytes + run_cell_spread(1, i & 7u); }
 		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
-			const uint32_t elem = LAYOUT == kLayoutVoxel ? BPV : 4u * BPV;   // bytes per element: a quad of voxels, or one voxel
+			const uint32_t elem = LAYOUT == kLayoutVoxel ? BPV : (LAYOUT == kLayoutOct ? 8u * BPV : 4u * BPV);   // bytes per element: one voxel, a quad, or the 2x2x2 neighbourhood
 			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
 			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t jj = t; jj < nz + 2 * kLutPad; jj += kThreads) {
@@ -791,12 +806,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			// the body is straight-line code with two wave-uniform branches (transparent shortcut, shading block).
 			uint64_t live = __builtin_amdgcn_ballot_w64(alive);
 			float step_v = kFree ? select_lanes(live, step) : step;       // per-lane step: 0 once the lane is finished
-			// kDepth samples ahead (one less for 2-byte voxels, whose slots hold four words: 64 VGPRs keep 8 waves per SIMD):
+			// kDepth samples ahead (three for 2-byte voxels, whose slots hold four words: 64 VGPRs keep 8 waves per SIMD):
 			// slot j carries the fetched words and the k of its sample
-			constexpr int kDepth = is_run_layout(LAYOUT) ? kRunDepth : (BPV == 1 ? vr::kDepth : (vr::kDepth > 1 ? vr::kDepth - 1 : 1)), kSlots = kDepth + 1;
+			constexpr int kDepth = is_run_layout(LAYOUT) ? kRunDepth : (BPV == 1 ? vr::kDepth : (vr::kDepth > kDepthTwoByte ? kDepthTwoByte : vr::kDepth)), kSlots = kDepth + 1;
 			TriFetch<BPV, LAYOUT> f[kSlots]; float ks[kSlots];
 			ks[0] = kx;
-			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0; f[kSlots - 1].q2 = 0;
+			f[kSlots - 1].w0 = f[kSlots - 1].w1 = f[kSlots - 1].w2 = f[kSlots - 1].w3 = 0; f[kSlots - 1].q = 0; f[kSlots - 1].q2 = 0; f[kSlots - 1].o = (u32x4) (0u);
 			static_for<0, kDepth>([&](auto j) {
 				if constexpr (j.value > 0) ks[j.value] = ks[j.value - 1] + step_v;
 				f[j.value] = issue(ks[j.value]);
@@ -825,6 +840,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				if (kManaged && is_run_layout(LAYOUT)) {               // one 8-byte gather per slot: kDepth younger ones may be in flight
 					pin(cur.q); managed_wait<kDepth>(); pin(cur.q);
 					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32);
+				} else if (kManaged && LAYOUT == kLayoutOct) {         // one 16-byte gather per slot (2-byte voxels, oct bricks)
+					pin(cur.o); managed_wait<kDepth>(); pin(cur.o);
+					cur.w0 = cur.o.x; cur.w1 = cur.o.y; cur.w2 = cur.o.z; cur.w3 = cur.o.w;
 				} else if (kManaged && BPV == 2) {                     // two 8-byte gathers per slot (2-byte voxels)
 					pin(cur.q, cur.q2); managed_wait<2 * kDepth>(); pin(cur.q, cur.q2);
 					cur.w0 = (uint32_t) cur.q; cur.w1 = (uint32_t) (cur.q >> 32); cur.w2 = (uint32_t) cur.q2; cur.w3 = (uint32_t) (cur.q2 >> 32);
@@ -888,7 +906,7 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 				}
 			}
 			if (kManaged) {                                            // nothing in flight into registers we release
-				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else if (BPV == 2) pin(f[j.value].q, f[j.value].q2); else pin(f[j.value].w0, f[j.value].w1); };
+				auto pin_slot = [&](auto j) { if (is_run_layout(LAYOUT)) pin(f[j.value].q); else if (LAYOUT == kLayoutOct) pin(f[j.value].o); else if (BPV == 2) pin(f[j.value].q, f[j.value].q2); else pin(f[j.value].w0, f[j.value].w1); };
 				static_for<0, kSlots>(pin_slot);
 				managed_wait<0>();
 				static_for<0, kSlots>(pin_slot);
@@ -934,6 +952,14 @@ static auto select_sampling(const RayKernelArgs &a, bool have_bricked, F &&visit
 			if (max_dim <= LutCfg<kAddr32>::max_dim && a.force_wide != 2)
 				return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutVoxel>(), false);
 			return visit(S(), V(), std::integral_constant<int, kAddrLut64>(), std::integral_constant<int, kLayoutVoxel>(), false);
+		}
+	}
+	if constexpr (!nearest && BPV == 2) {
+		if (have_bricked && a.layout == kLayoutOct) {
+			const uint64_t bytes = bricked_elems(a.dim_x, a.dim_y, a.dim_z) * 8 * BPV;
+			if (!a.force_wide && max_dim <= LutCfg<kAddr32>::max_dim && bytes <= (1ull << 32))
+				return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutOct>(), false);
+			return visit(S(), V(), std::integral_constant<int, kAddrLut64>(), std::integral_constant<int, kLayoutOct>(), false);
 		}
 	}
 	if (have_bricked && a.layout == kLayoutBricked) {
@@ -1091,6 +1117,39 @@ hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint
 	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
 	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
+	return hipGetLastError();
+}
+
+// linear -> oct bricks (2-byte voxels): element o of the 2-byte brick order holds the 2x2x2 neighbourhood of its cell, indices
+// clamped at the upper faces (the clamped neighbours only ever get weight 0); 16 bytes per element, written as one uint4
+__global__ __launch_bounds__(256)
+void brickify_oct_kernel(const uint16_t *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
+                         uint32_t nbx, uint32_t nby, uint32_t nbz) {
+	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
+	const uint64_t stride = (uint64_t) gridDim.x * 256;
+	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
+		const uint64_t brick = o / kBrickPitch;
+		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
+		const uint32_t lz = brick_collect(2, kPlaneXY, 2, local), lx = brick_collect(2, kPlaneXY, 0, local), ly = brick_collect(2, kPlaneXY, 1, local);
+		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
+		const uint32_t by = br / nbx, bx = br - by * nbx;
+		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
+		uint4 e = { 0u, 0u, 0u, 0u };
+		if (x < dim_x && y < dim_y && z < dim_z) {
+			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1, z1 = z + 1 < dim_z ? z + 1 : dim_z - 1;
+			const uint16_t *s0 = lin + (uint64_t) z * dim_y * dim_x, *s1 = lin + (uint64_t) z1 * dim_y * dim_x;
+			e.x = s0[(uint64_t) y * dim_x + x] | ((uint32_t) s0[(uint64_t) y * dim_x + x1] << 16);
+			e.y = s0[(uint64_t) y1 * dim_x + x] | ((uint32_t) s0[(uint64_t) y1 * dim_x + x1] << 16);
+			e.z = s1[(uint64_t) y * dim_x + x] | ((uint32_t) s1[(uint64_t) y * dim_x + x1] << 16);
+			e.w = s1[(uint64_t) y1 * dim_x + x] | ((uint32_t) s1[(uint64_t) y1 * dim_x + x1] << 16);
+		}
+		out[o] = e;
+	}
+}
+
+hipError_t launch_brickify_oct(const void *linear, void *oct_bricks, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge, nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
+	hipLaunchKernelGGL(brickify_oct_kernel, dim3(16384), dim3(256), 0, stream, (const uint16_t *) linear, (uint4 *) oct_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
 	return hipGetLastError();
 }
 
