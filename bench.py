@@ -273,12 +273,12 @@ def run_rank(a):
         # work.wait() makes it wait for RCCL before the buffer pair is rendered into again.
         render_stream = torch.cuda.Stream(device)
         stream_ctx, stream = torch.cuda.stream(render_stream), render_stream.cuda_stream
-        # N >= 3: a rank's share of the frame no longer fills the chip for long (at N = 8 it is exactly one load of 8192 waves, marching
+        # N >= 2: a rank's share of the frame no longer fills the chip for long (at N = 8 it is exactly one load of 8192 waves, marching
         # in lockstep), so the two frames a rank has in flight are RENDERED concurrently, each slot on a stream of its own — measured on
-        # one GPU with the band sets of an N-rank run (scale_model.pipelined_*): N = 4: 0.87 -> 0.63 ms per frame, N = 8: 0.58 -> 0.37;
-        # at N = 2 a share is still two loads and concurrency costs 8 %, at N = 1 one frame fills the chip: both slots share one stream
-        # there (kernel_ms then is the kernel's own duration).
-        two_streams = world >= 3 or os.environ.get("VR_BENCH_TWO_STREAMS") == "1"      # the env switch rehearses the pipeline on one GPU
+        # one GPU with the band sets of an N-rank run (scripts/overlap_probe.py, scale_model.pipelined_*): N = 2: 1.41 -> 1.19 ms per
+        # frame, N = 4: 0.87 -> 0.62, N = 8: 0.57 -> 0.36.  At N = 1 one frame fills the chip (2.44 -> 2.41) and both slots share one
+        # stream, so that kernel_ms is the kernel's own duration.
+        two_streams = world >= 2 or os.environ.get("VR_BENCH_TWO_STREAMS") == "1"      # the env switch rehearses the pipeline on one GPU
         slot_streams = [render_stream, torch.cuda.Stream(device) if two_streams else render_stream]
 
     import contextlib
@@ -431,7 +431,7 @@ def run_rank(a):
                 "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
                                          "(every other TRILINEAR view), 4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
-                "kernel_ms_note": ("N >= 3: the two frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
+                "kernel_ms_note": ("N >= 2: the two frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
                                    "launch that shares the chip with its neighbour — longer than the kernel alone; `value` (frames per second over all ranks) is the figure "
                                    "that counts, `scale_model` at N = 1 holds the per-rank kernel times without overlap") if slot_streams[0] is not slot_streams[1] else None,
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
@@ -495,6 +495,9 @@ def run_rank(a):
                                                           "4 two-voxel loads per sample — north_star's literal layout, timed beside the product's brick copies"}
                 if "multi" in legs:
                     out["extras"]["multi_overhead"] = bx.multi_overhead(vr, local_rank)
+                if "modes" in legs:
+                    set_mode(scene, a.mode)
+                    out["extras"]["two_frames_concurrent"] = bx.concurrent_frames_leg(vr, r, params, local[0])
             if world == 1 and not a.no_cpu_baseline and bpv == 1:
                 out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
                 # the comparison north_star asks for, labelled — vs_baseline itself stays null (BASELINE.md has no published number)

@@ -10,10 +10,10 @@
 //     available or the device list names one GPU twice (how the path is tested on a one-GPU box);
 //   * a copy kernel on device 0 de-interleaves the bands into the caller's frame;
 //   * TWO frames in flight (vr_hip_multi_render_device_async + vr_hip_multi_sync): band buffers, staging, timing events AND STREAMS
-//     exist twice — from three devices on the two frames render concurrently, each slot on streams of its own: a device's share of a
-//     frame then fills the chip only briefly (at 8 devices: one load of waves marching in lockstep), and two such shares side by side
-//     keep it busy (measured with the band sets of an N-rank run on one GPU, bench.py scale_model: N = 4 0.87 -> 0.63 ms per frame,
-//     N = 8 0.58 -> 0.37; at N = 2 concurrency costs 8 %, so one and two devices keep one stream per device for both slots);
+//     exist twice — with two or more devices the two frames render concurrently, each slot on streams of its own: a device's share
+//     of a frame then fills the chip only briefly (at 8 devices: one load of waves marching in lockstep), and two such shares side by
+//     side keep it busy (measured with the band sets of an N-rank run on one GPU, scripts/overlap_probe.py: N = 2 1.41 -> 1.19 ms per
+//     frame, N = 4 0.87 -> 0.62, N = 8 0.57 -> 0.36); a single device keeps one stream for both slots (a whole frame fills the chip);
 //     frame i+1 also renders while the bands of frame i travel and are assembled; nothing is created or destroyed per frame.
 //     vr_hip_multi_render_device / vr_hip_multi_render are the synchronous calls the reference's interface needs (async + sync).
 // Built only on the public single-device ABI + the HIP runtime: nothing here touches vr_ctx internals.
@@ -236,8 +236,8 @@ int vr_hip_multi_create(int n, const int *devices, vr_multi **out) {
 		if (rc != VR_OK) return fail(m, rc, m->ctx[r] ? vr_hip_last_error(m->ctx[r]) : "vr_hip_create failed");
 		VRM_TRY(m, hipSetDevice(devices[r]));
 		VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[0][r], hipStreamNonBlocking));
-		if (n >= 3) VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[1][r], hipStreamNonBlocking));
-		else m->streams[1][r] = m->streams[0][r];             // one and two devices: both slots on one stream
+		if (n >= 2) VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[1][r], hipStreamNonBlocking));
+		else m->streams[1][r] = m->streams[0][r];             // one device: both slots on one stream
 		for (int s = 0; s < kFrames; s++) VRM_TRY(m, hipEventCreateWithFlags(&m->rendered[s][r], hipEventDisableTiming));
 	}
 	VRM_TRY(m, hipSetDevice(devices[0]));
