@@ -20,6 +20,10 @@
 
 using namespace vr;
 
+#ifndef VR_ORDER_ALWAYS
+#define VR_ORDER_ALWAYS 0      // 1: the measured-cost tile order also for the full march (A/B: TRILINEAR +2 %, NEAREST -2 %)
+#endif
+
 namespace {
 
 constexpr int kEventRing = 256;
@@ -300,7 +304,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	uint32_t run_layout = kLayoutRun;        // which run copy a run-brick frame reads: runs along z unless the view marches along z
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
-	// Copies are built on first use (copy_for): `have` asks without building.
+	// Copies are built on first use (copy_for, further down); copy_possible asks without building.
 	a.brick_plane = kPlaneXY;
 	if (p->sampling != VR_SAMPLE_NEAREST && bricked && !c->force_wide) {
 		uint32_t plane = kPlaneXY;
@@ -405,16 +409,14 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
 	bool record = false;
 	TileSchedule sched;
-#ifndef VR_ORDER_ALWAYS
-#define VR_ORDER_ALWAYS 0
-#endif
 	if (hit != nullptr && c->tile_scheduling == 1 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
 		if (hit->order_state >= 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
 		if (hit->order_state >= 1) {
 			// built on another stream: this frame must not read the order before the kernel that writes it has run
 			if (stream != hit->order_stream) VR_TRY(c, hipStreamWaitEvent(stream, hit->order_ready, 0));
-			sched.order = hit->order + (hit->order_state == 2 ? hit->capacity : 0u);     // the second order lives in the second half: a frame
-			if (hit->order_state == 1 && stream == hit->order_stream) {                  // still running on another stream keeps reading the first          // second recording, under the first order (cost[] was cleared by the order kernel)
+			// the second order lives in the second half of the buffer: a frame still running on another stream keeps reading the first
+			sched.order = hit->order + (hit->order_state == 2 ? hit->capacity : 0u);
+			if (hit->order_state == 1 && stream == hit->order_stream) {      // second recording, under the first order (the order kernel cleared cost[])
 				sched.cost = hit->cost;
 				record = true;
 			}
