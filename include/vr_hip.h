@@ -152,8 +152,9 @@ int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
 int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
 /* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
- * lane_map -1 = chosen per frame from the view (default); 0 = 4 pixels along screen x, 1 = along screen y, 2 = 2x2-pixel
- * blocks; phase_x / phase_y (0..7) shift the tile grid left / down (ignored when lane_map is -1).  Testing and tuning aid
+ * lane_map -1 = chosen per frame from the view (default); else (lane order) + 4 * (wave shape): order 0 = 4 pixels along screen x,
+ * 1 = along screen y, 2 = 2x2-pixel blocks; wave shape 0 = 8x8 pixels per wavefront, 1 = 16 wide x 4 high, 2 = 4 wide x 16 high;
+ * phase_x / phase_y (0..7) shift the tile grid left / down (ignored when lane_map is -1).  Testing and tuning aid
  * (tests force every combination and compare the images).  No reference counterpart. */
 int vr_hip_set_tile_mapping(vr_ctx *ctx, int32_t lane_map, uint32_t phase_x, uint32_t phase_y);
 

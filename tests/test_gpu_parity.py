@@ -236,8 +236,8 @@ def test_tile_mapping_never_changes_the_image(vr, gpu, golden, oracle):
                 ref = oracle.render(p, vox8, st["tf"], st["esl"])
                 gpu.set_tile_mapping(-1)
                 assert np.array_equal(gpu.render_volume(p), ref), (case["label"], mode, "auto")
-                for lane_map in (0, 1, 2):
-                    for px, py in ((0, 0), (1, 0), (3, 2), (7, 7), (5, 0)):
+                for lane_map in (0, 1, 2, 4, 5, 6, 8, 9, 10):                 # lane order + 4 * wave shape (8x8, 16x4, 4x16)
+                    for px, py in ((0, 0), (1, 0), (3, 2), (7, 7), (5, 0)) if lane_map < 3 else ((0, 0), (3, 6)):
                         gpu.set_tile_mapping(lane_map, px, py)
                         assert np.array_equal(gpu.render_volume(p), ref), (case["label"], mode, lane_map, px, py)
         # banded partition (rank 1 of 3, 16-row bands) with a shifted grid

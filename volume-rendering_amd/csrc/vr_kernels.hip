@@ -600,11 +600,17 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	// memory pipeline handles 4 consecutive lanes together and is fastest when their addresses share one aligned 16-byte
 	// chunk, so the 4 lanes should be the 4 pixels whose samples lie closest together in the brick order.
 	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;                             // kLaneRows: lanes run along screen x
-	if (a.lane_map == kLaneBlocks) { gu = ((lane >> 1) & 2u) | (lane & 1u); gv = ((lane >> 2) & 2u) | ((lane >> 1) & 1u); }
-	else if (a.lane_map == kLaneColumns) { const uint32_t t = gu; gu = gv; gv = t; }
-	const uint32_t wx = (qd & 1u) * 4u + gu, wy = (qd >> 1) * 4u + gv;
-	const uint32_t lx = tile_x * 32u + (wave & 3u) * 8u + wx - a.phase_x;      // wraps for the pixels left of / below the buffer
-	const uint32_t ly = tile_y * (kThreads / 32u) + (wave >> 2) * 8u + wy - a.phase_y;
+	const uint32_t order = a.lane_map & 3u, shape = kThreads == 512u ? (a.lane_map >> 2) : 0u;
+	if (order == kLaneBlocks) { gu = ((lane >> 1) & 2u) | (lane & 1u); gv = ((lane >> 2) & 2u) | ((lane >> 1) & 1u); }
+	else if (order == kLaneColumns) { const uint32_t t = gu; gu = gv; gv = t; }
+	// Shape of the wave's pixel tile inside the 32x16-pixel workgroup tile (bits 2.. of lane_map): 0 = 8x8 (four 4x4 groups as 2x2),
+	// 1 = 16 wide x 4 high (the groups side by side; the 8 waves 2 across x 4 down), 2 = 4 wide x 16 high (8 waves across).
+	uint32_t wx, wy, ox, oy;
+	if (shape == 1u) { wx = qd * 4u + gu; wy = gv; ox = (wave & 1u) * 16u; oy = (wave >> 1) * 4u; }
+	else if (shape == 2u) { wx = gu; wy = qd * 4u + gv; ox = wave * 4u; oy = 0u; }
+	else { wx = (qd & 1u) * 4u + gu; wy = (qd >> 1) * 4u + gv; ox = (wave & 3u) * 8u; oy = (wave >> 2) * 8u; }
+	const uint32_t lx = tile_x * 32u + ox + wx - a.phase_x;                      // wraps for the pixels left of / below the buffer
+	const uint32_t ly = tile_y * (kThreads / 32u) + oy + wy - a.phase_y;
 	if (lx >= a.p.out_width || ly >= a.p.out_rows)
 		return;                                     // no barrier below this point
 	const uint32_t band = ly / a.p.band_rows;
