@@ -211,6 +211,12 @@ def run_rank(a):
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # The HIP runtime gives a process 4 hardware queues per device by default and lets further streams SHARE them (a stream takes its
+    # queue at first use).  A rank uses the slot streams below, torch's default stream and the RCCL stream: with 4 queues two slot
+    # streams can land on one queue and their frames serialise (measured, scripts/gpu_r03_x.sh: two slot streams beside two other
+    # busy streams 0.565 ms per frame = no overlap at all, against 0.356 with queues of their own).  Read by the runtime when it
+    # initialises, so it is set before torch is imported.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import importlib
     import torch
     import torch.distributed as dist
@@ -273,27 +279,30 @@ def run_rank(a):
         # work.wait() makes it wait for RCCL before the buffer pair is rendered into again.
         render_stream = torch.cuda.Stream(device)
         stream_ctx, stream = torch.cuda.stream(render_stream), render_stream.cuda_stream
-        # N >= 2: a rank's share of the frame no longer fills the chip for long (at N = 8 it is exactly one load of 8192 waves, marching
-        # in lockstep), so the two frames a rank has in flight are RENDERED concurrently, each slot on a stream of its own — measured on
-        # one GPU with the band sets of an N-rank run (scripts/overlap_probe.py, scale_model.pipelined_*): N = 2: 1.41 -> 1.19 ms per
-        # frame, N = 4: 0.87 -> 0.62, N = 8: 0.57 -> 0.36.  At N = 1 one frame fills the chip (2.44 -> 2.41) and both slots share one
-        # stream, so that kernel_ms is the kernel's own duration.
-        two_streams = world >= 2 or os.environ.get("VR_BENCH_TWO_STREAMS") == "1"      # the env switch rehearses the pipeline on one GPU
-        slot_streams = [render_stream, torch.cuda.Stream(device) if two_streams else render_stream]
+        # N >= 2: a rank's share of the frame no longer fills the chip for long (at N = 8 it is exactly one load of 8192 waves: the
+        # launch lasts as long as its longest wave while the mean wave is much shorter), so a rank keeps THREE frames in flight and
+        # renders them concurrently, each slot on a stream of its own — the next frames' workgroups fill the tail of the one before.
+        # Measured on one GPU with the band sets of an N-rank run (scripts/overlap_probe.py, scale_model.pipelined_*), ms per frame with
+        # 1 / 2 / 3 / 4 streams: N = 2: 1.40 / 1.18 / 1.16 / 1.20, N = 4: 0.86 / 0.60 / 0.59 / 0.65, N = 8: 0.57 / 0.36 / 0.29 / 0.35.
+        # At N = 1 one frame fills the chip (2.39 -> 2.29 with two) and the two slots share one stream, so that kernel_ms is the
+        # kernel's own duration.
+        many_streams = world >= 2 or os.environ.get("VR_BENCH_TWO_STREAMS") == "1"     # the env switch rehearses the pipeline on one GPU
+        slot_streams = [render_stream] + [torch.cuda.Stream(device) for _ in range(2)] if many_streams else [render_stream, render_stream]
 
     import contextlib
     if a.dry_run:
-        slot_streams = [None, None]
+        slot_streams = [None] * (3 if world >= 2 else 2)
+    slots = len(slot_streams)
 
     def on_slot(slot):
         return contextlib.nullcontext() if slot_streams[slot] is None else torch.cuda.stream(slot_streams[slot])
 
-    # two frames in flight: frame i+1 is rendered while the bands of frame i travel to rank 0 on the backend's stream
-    local = [split.local_buffer(device) for _ in range(2)]
-    staging = [split.staging_buffer(device) if (rank == 0 and distributed) else None for _ in range(2)]
-    pending = [None, None]
+    # `slots` frames in flight: frame i+1 is rendered while the bands of frame i travel to rank 0 on the backend's stream
+    local = [split.local_buffer(device) for _ in range(slots)]
+    staging = [split.staging_buffer(device) if (rank == 0 and distributed) else None for _ in range(slots)]
+    pending = [None] * slots
     # the assembled frame (what a display or an encoder would consume) lives on rank 0, one per slot
-    final = [torch.empty((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)]
+    final = [torch.empty((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(slots)]
 
     def render(i, slot):
         if a.dry_run:
@@ -315,14 +324,14 @@ def run_rank(a):
         pending[slot] = None
 
     def step(i):
-        slot = i & 1
+        slot = i % slots
         with on_slot(slot):                         # render, gather and de-interleave of a slot are ordered through the slot's stream
-            retire(slot)                            # the buffer pair of frame i-2 is free again
+            retire(slot)                            # the buffers of frame i - slots are free again
             render(i, slot)
             pending[slot] = split.gather_async(local[slot], staging[slot])
 
     def fence():
-        for slot in (0, 1):
+        for slot in range(slots):
             with on_slot(slot):
                 retire(slot)
         if distributed:
@@ -357,11 +366,11 @@ def run_rank(a):
             return None
         if a.dry_run:
             want = ((torch.arange(H) + i) % 251).to(torch.uint8).view(-1, 1, 1).expand(-1, W, 4)
-            return "ok" if torch.equal(final[i & 1], want) else "MISMATCH"
+            return "ok" if torch.equal(final[i % slots], want) else "MISMATCH"
         whole = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
         r.render_volume_device(vr.whole_frame(scene.frame_params(views[i % 8], sampling)), whole.data_ptr(), stream)
         torch.cuda.synchronize()
-        return "ok" if torch.equal(final[i & 1], whole) else "MISMATCH"
+        return "ok" if torch.equal(final[i % slots], whole) else "MISMATCH"
 
     if stream_ctx is not None:
         with stream_ctx:
@@ -389,7 +398,7 @@ def run_rank(a):
         ms_per_step = elapsed / a.steps * 1e3
         mrays = W * H / (elapsed / a.steps) / 1e6
         partition = (f"{world} rank(s) x interleaved {band_rows}-row bands, "
-                     f"{'gloo' if a.dry_run else 'RCCL'} gather to rank 0, 2 frames in flight"
+                     f"{'gloo' if a.dry_run else 'RCCL'} gather to rank 0, {slots} frames in flight"
                      f"{' rendered concurrently (one stream per slot)' if slot_streams[0] is not slot_streams[1] else ''}") if distributed else "single GPU, whole frame"
         out = {
             "metric": f"Mrays/s (W*H / t_frame), {n}^3 volume @ {W}x{H} viewport" if (n, W, H) != (1024, 2048, 2048) else
@@ -431,7 +440,7 @@ def run_rank(a):
                 "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
                                          "(every other TRILINEAR view), 4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
-                "kernel_ms_note": ("N >= 2: the two frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
+                "kernel_ms_note": ("N >= 2: the three frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
                                    "launch that shares the chip with its neighbour — longer than the kernel alone; `value` (frames per second over all ranks) is the figure "
                                    "that counts, `scale_model` at N = 1 holds the per-rank kernel times without overlap") if slot_streams[0] is not slot_streams[1] else None,
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),

@@ -204,8 +204,8 @@ int vr_hip_download_volume(vr_ctx *ctx, void *host_out, uint64_t bytes);
  * available or a device is listed twice — and a copy kernel there de-interleaves them.  `params` describe the WHOLE frame
  * (partition fields are ignored); the image equals the single-device image byte for byte.
  * vr_hip_multi_render / _render_device are synchronous, like every renderer call of the reference.  _render_device_async queues
- * a frame and returns: two frames are in flight (band buffers, staging and events exist twice; nothing is created per frame),
- * frame i+1 renders while the bands of frame i travel; `consumer_stream` (hipStream_t on devices[0], may be NULL) is made to wait
+ * a frame and returns: up to three frames are in flight (band buffers, staging, events and per-device streams exist three times; nothing
+ * is created per frame; the frames in flight must not share `dev_rgba`), frame i+1 renders while the bands of frame i travel; `consumer_stream` (hipStream_t on devices[0], may be NULL) is made to wait
  * for the assembled frame; vr_hip_multi_sync waits for everything queued.
  * A one-entry list is the single-device path.  The reference's `renderers[id]->render_volume()` reaches this through
  * volr::HipRenderer's device-list constructor (volume-rendering_amd/csrc/host/Renderer.h).

@@ -103,10 +103,10 @@ def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ra
     view; predicted efficiency = mean over views of t_1 / (N * max_r t_r) — load balance only, no gather, no host overhead."""
     out = {"what": "each rank's bands rendered alone on this GPU (kernel ms, hipEvents); efficiency = mean_v t1(v) / (N * max_r t_r(v)); "
                    "load balance only — the gather (16 MiB / N per rank over xGMI) and host overhead are not in it.  pipelined_*: rank 0's bands of "
-                   "consecutive frames rendered CONCURRENTLY on two streams, as the N-rank run does (wall ms per frame over 32 frames): a rank's share "
+                   "consecutive frames rendered CONCURRENTLY on three streams (three frames in flight), as the N-rank run does (wall ms per frame over 48 frames): a rank's share "
                    "of a frame fills the chip only briefly, two of them side by side keep it busy"}
-    two = [torch.cuda.Stream(), torch.cuda.Stream()]
-    buf2 = torch.empty_like(buf)
+    three = [torch.cuda.Stream() for _ in range(3)]
+    bufs3 = [buf, torch.empty_like(buf), torch.empty_like(buf)]
     for mode in modes:
         set_mode(scene, mode)
         whole = [vr.whole_frame(scene.frame_params(v, sampling)) for v in views]
@@ -128,10 +128,10 @@ def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ra
             for attempt in range(2):                         # the first pass warms the second stream's queue up
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for i in range(32):
-                    r.render_volume_device(ps0[i % len(ps0)], (buf if i & 1 == 0 else buf2).data_ptr(), two[i & 1].cuda_stream)
+                for i in range(48):
+                    r.render_volume_device(ps0[i % len(ps0)], bufs3[i % 3].data_ptr(), three[i % 3].cuda_stream)
                 torch.cuda.synchronize()
-                piped = (time.perf_counter() - t0) / 32 * 1e3
+                piped = (time.perf_counter() - t0) / 48 * 1e3
             res[f"n{n}"] = {"band_rows": band_rows, "per_rank_kernel_ms": [round(x, 4) for x in per_rank],
                             "pipelined_ms_per_frame": round(piped, 4), "predicted_efficiency_pipelined": round(sum(t1) / len(t1) / (n * piped), 4),
                             "max_over_mean": round(max(per_rank) / (sum(per_rank) / n), 4),
@@ -146,7 +146,7 @@ def multi_overhead(vr, device_index=0, n_volume=256, W=2048, H=2048, lists=(1, 2
     device 0.  Small volume (256^3: kernel time is a fraction of a millisecond), the headline viewport (the band copies and the
     assemble kernel move the real 16 MiB): wall ms per frame, synchronous call against the two-frames-in-flight pipeline."""
     out = {"what": f"vr_hip_multi_* with device lists [0]*N on one GPU, shell {n_volume}^3 @ {W}x{H}, full march TRILINEAR, view 1; wall ms per frame "
-                   f"over {frames} frames: synchronous calls / async pipeline (2 frames in flight); kernel_ms_sum = sum of the N band kernels of a frame"}
+                   f"over {frames} frames: synchronous calls / async pipeline (3 frames in flight); kernel_ms_sum = sum of the N band kernels of a frame"}
     r0 = vr.HipRenderer(device_index)                       # the scene (TF, ESL, ray step) of this volume, by the feeders
     try:
         r0.generate_volume("shell", n_volume, seed=1)
@@ -161,18 +161,18 @@ def multi_overhead(vr, device_index=0, n_volume=256, W=2048, H=2048, lists=(1, 2
             m.set_window_buffer(W, H)
             m.generate_volume("shell", n_volume, seed=1)
             m.set_transfer_fn(scene.tf, scene.esl)
-            bufs = [torch.empty((H, W, 4), dtype=torch.uint8, device=f"cuda:{device_index}") for _ in range(2)]
+            bufs = [torch.empty((H, W, 4), dtype=torch.uint8, device=f"cuda:{device_index}") for _ in range(3)]
             torch.cuda.synchronize()
             for _ in range(3):
                 m.render_volume_device(p, bufs[0].data_ptr())
             t0 = time.perf_counter()
             for i in range(frames):
-                m.render_volume_device(p, bufs[i & 1].data_ptr())
+                m.render_volume_device(p, bufs[i % 3].data_ptr())
             sync_ms = (time.perf_counter() - t0) / frames * 1e3
             per, _ = m.timing()
             t0 = time.perf_counter()
             for i in range(frames):
-                m.render_volume_device_async(p, bufs[i & 1].data_ptr())
+                m.render_volume_device_async(p, bufs[i % 3].data_ptr())
             m.sync()
             async_ms = (time.perf_counter() - t0) / frames * 1e3
             out[f"n{n}"] = {"transport": m.transport, "sync_ms_per_frame": round(sync_ms, 4), "pipelined_ms_per_frame": round(async_ms, 4),

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--mode", default="nooptims")
     ap.add_argument("--skip-streams", type=int, default=0)
+    ap.add_argument("--streams", default="1,2", help="numbers of streams (= frames in flight rendering concurrently) to compare")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = the default rule)")
     a = ap.parse_args()
     vr = importlib.import_module("volume-rendering_amd")
@@ -33,20 +34,25 @@ def main():
     r.set_transfer_fn(scene.tf, scene.esl)
     views = [vr.benchmark_view(W, W, i) for i in range(8)]
     out = {}
-    spare = [torch.cuda.Stream() for _ in range(a.skip_streams)]      # moves the pair to other slots of torch's stream pool
-    pair = [torch.cuda.Stream() for _ in range(2)]
+    spare = [torch.cuda.Stream() for _ in range(a.skip_streams)]      # other streams of the process that hold a hardware queue
+    for sp in spare:
+        with torch.cuda.stream(sp):
+            torch.zeros(16, device="cuda:0").add_(1)
+    torch.cuda.synchronize()
+    counts = [int(x) for x in a.streams.split(",")]
+    pair = [torch.cuda.Stream() for _ in range(max(counts))]
     for world in [int(x) for x in a.ranks.split(",")]:
         split = dmod.FrameSplit(W, W, world, 0, a.band_rows or None)
         ps = [split.apply(scene.frame_params(v, vr.SAMPLE_TRILINEAR)) for v in views]
-        bufs = [split.local_buffer("cuda:0") for _ in range(2)]
+        bufs = [split.local_buffer("cuda:0") for _ in range(max(counts))]
         streams = pair                                         # ONE pair of streams for every measurement of the run
         for p in ps:
             for _ in range(3):
                 r.render_volume_device(p, bufs[0].data_ptr(), streams[0].cuda_stream)
         torch.cuda.synchronize()
-        res = {"one_stream": [], "two_streams": []}
+        res = {f"streams_{c}": [] for c in counts}
         for rep in range(3):                                   # interleaved repetitions: one, two, one, two, ...
-            for label, nstreams in (("one_stream", 1), ("two_streams", 2)):
+            for label, nstreams in ((f"streams_{c}", c) for c in counts):
                 t0 = time.perf_counter()
                 for i in range(a.frames):
                     s = i % nstreams

@@ -59,7 +59,7 @@ def test_gloo_frame_split_equals_single_rank(tmp_path, oracle, golden, world, ba
 
 
 def _pipelined_worker(rank, world, port, out_path):
-    """bench.py's step loop on gloo: two frames in flight (double-buffered local / staging buffers), gather_async, retire."""
+    """bench.py's step loop on gloo: three frames in flight (one local / staging buffer per slot), gather_async, retire."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -74,9 +74,10 @@ def _pipelined_worker(rank, world, port, out_path):
         st = golden.volume_state(cases[0]["volume"])
         vox = golden.voxels(cases[0]["volume"])
         split = dmod.FrameSplit(64, 64, world, rank, 16)
-        local = [split.local_buffer("cpu") for _ in range(2)]
-        staging = [split.staging_buffer("cpu") if rank == 0 else None for _ in range(2)]
-        pending = [None, None]
+        slots = 3
+        local = [split.local_buffer("cpu") for _ in range(slots)]
+        staging = [split.staging_buffer("cpu") if rank == 0 else None for _ in range(slots)]
+        pending = [None] * slots
         done = []
 
         def retire(slot):
@@ -90,13 +91,13 @@ def _pipelined_worker(rank, world, port, out_path):
             pending[slot] = None
 
         for i, case in enumerate(cases):
-            slot = i & 1
+            slot = i % slots
             retire(slot)
             p = split.apply(golden.params(case, sampling=1))
             local[slot].copy_(torch.from_numpy(oracle.render(p, vox, st["tf"], st["esl"], threads=2)))
             pending[slot] = split.gather_async(local[slot], staging[slot])
-        retire(len(cases) & 1)
-        retire((len(cases) + 1) & 1)
+        for k in range(slots):                              # oldest first
+            retire((len(cases) + k) % slots)
         dist.barrier()
         if rank == 0:
             assert len(done) == len(cases)

@@ -386,8 +386,8 @@ def test_multi_device_frame_equals_single_device(vr, gpu, golden):
 
 def test_multi_device_pipeline_rccl_self_and_selfcheck(vr, gpu, golden, monkeypatch):
     """The parts of the several-GPU path that one GPU can execute:
-    * two frames in flight (vr_hip_multi_render_device_async / _sync): 8 different frames queued back to back into 8 buffers —
-      every one equals the single-device frame, so no band buffer of frame i was overwritten by frame i+1 or i+2;
+    * three frames in flight (vr_hip_multi_render_device_async / _sync): 8 different frames queued back to back into 8 buffers —
+      every one equals the single-device frame, so no band buffer of frame i was overwritten by frames i+1 … i+3;
     * VR_MULTI_TRANSPORT=rccl-self: the bands travel through ncclSend / ncclRecv (one communicator, peer = self) — dlopen of
       librccl, ncclCommInitAll, the grouped calls and their stream ordering run on hardware;
     * VR_MULTI_SELFCHECK=1: the first-frame self-check (device 0's own render of the other ranks' bands against what arrived)

@@ -9,11 +9,12 @@
 //     ncclCommInitAll; librccl is dlopen'ed so that single-GPU users never need it), or plain peer copies when RCCL is not
 //     available or the device list names one GPU twice (how the path is tested on a one-GPU box);
 //   * a copy kernel on device 0 de-interleaves the bands into the caller's frame;
-//   * TWO frames in flight (vr_hip_multi_render_device_async + vr_hip_multi_sync): band buffers, staging, timing events AND STREAMS
-//     exist twice — with two or more devices the two frames render concurrently, each slot on streams of its own: a device's share
-//     of a frame then fills the chip only briefly (at 8 devices: one load of waves marching in lockstep), and two such shares side by
-//     side keep it busy (measured with the band sets of an N-rank run on one GPU, scripts/overlap_probe.py: N = 2 1.41 -> 1.19 ms per
-//     frame, N = 4 0.87 -> 0.62, N = 8 0.57 -> 0.36); a single device keeps one stream for both slots (a whole frame fills the chip);
+//   * THREE frames in flight (vr_hip_multi_render_device_async + vr_hip_multi_sync): band buffers, staging, timing events AND STREAMS
+//     exist three times — with two or more devices the frames render concurrently, each slot on streams of its own: a device's share
+//     of a frame fills the chip only briefly (at 8 devices: one load of waves, and the launch lasts as long as its longest wave), and
+//     the next frames' workgroups fill that tail (measured with the band sets of an N-rank run on one GPU, scripts/overlap_probe.py,
+//     ms per frame with 1 / 2 / 3 / 4 streams: N = 2 1.40 / 1.18 / 1.16 / 1.20, N = 4 0.86 / 0.60 / 0.59 / 0.65, N = 8 0.57 / 0.36 /
+//     0.29 / 0.35); a single device keeps one stream for every slot (a whole frame fills the chip);
 //     frame i+1 also renders while the bands of frame i travel and are assembled; nothing is created or destroyed per frame.
 //     vr_hip_multi_render_device / vr_hip_multi_render are the synchronous calls the reference's interface needs (async + sync).
 // Built only on the public single-device ABI + the HIP runtime: nothing here touches vr_ctx internals.
@@ -68,7 +69,7 @@ struct Rccl {
 };
 
 enum Transport { kSingle = 0, kRccl = 1, kPeerCopy = 2, kRcclSelf = 3 };
-constexpr int kFrames = 2;       // frames in flight
+constexpr int kFrames = 3;       // frames in flight
 
 }  // namespace
 
@@ -76,14 +77,14 @@ struct vr_multi {
 	int n = 0;
 	std::vector<int> dev;
 	std::vector<vr_ctx *> ctx;
-	std::vector<hipStream_t> streams[2];             // [slot][rank]: the two frames in flight run on streams of their own
+	std::vector<hipStream_t> streams[kFrames];       // [slot][rank]: the frames in flight run on streams of their own
 	// per frame slot
 	std::vector<hipEvent_t> rendered[kFrames];      // rank r's bands of the slot's frame are rendered (recorded on stream[r])
 	std::vector<void *> local[kFrames];             // rank r's bands on its own device (rank 0: its slice of staging[slot])
-	void *staging[kFrames] = { nullptr, nullptr };  // device 0: [n][local_rows][width] RGBA8
-	hipEvent_t gathered[kFrames] = { nullptr, nullptr };   // device 0 has read every local[r] of the slot (peer-copy transport)
-	hipEvent_t t0[kFrames] = { nullptr, nullptr }, t1[kFrames] = { nullptr, nullptr };   // device-0 stream time of the slot's frame
-	bool in_flight[kFrames] = { false, false };
+	void *staging[kFrames] = {};                    // device 0: [n][local_rows][width] RGBA8
+	hipEvent_t gathered[kFrames] = {};              // device 0 has read every local[r] of the slot (peer-copy transport)
+	hipEvent_t t0[kFrames] = {}, t1[kFrames] = {};  // device-0 stream time of the slot's frame
+	bool in_flight[kFrames] = {};
 	uint64_t frames = 0;                            // frames queued since create
 	void *frame0 = nullptr;                         // device 0: assembled frame of the host-buffer entry point
 	void *check = nullptr;                          // device 0: self-check scratch (one band slice) + mismatch counter
@@ -236,8 +237,10 @@ int vr_hip_multi_create(int n, const int *devices, vr_multi **out) {
 		if (rc != VR_OK) return fail(m, rc, m->ctx[r] ? vr_hip_last_error(m->ctx[r]) : "vr_hip_create failed");
 		VRM_TRY(m, hipSetDevice(devices[r]));
 		VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[0][r], hipStreamNonBlocking));
-		if (n >= 2) VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[1][r], hipStreamNonBlocking));
-		else m->streams[1][r] = m->streams[0][r];             // one device: both slots on one stream
+		for (int s = 1; s < kFrames; s++) {
+			if (n >= 2) VRM_TRY(m, hipStreamCreateWithFlags(&m->streams[s][r], hipStreamNonBlocking));
+			else m->streams[s][r] = m->streams[0][r];         // one device: every slot on one stream
+		}
 		for (int s = 0; s < kFrames; s++) VRM_TRY(m, hipEventCreateWithFlags(&m->rendered[s][r], hipEventDisableTiming));
 	}
 	VRM_TRY(m, hipSetDevice(devices[0]));
@@ -292,7 +295,7 @@ void vr_hip_multi_destroy(vr_multi *m) {
 	for (int r = 0; r < m->n; r++) {
 		(void) hipSetDevice(m->dev[r]);
 		for (int s = 0; s < kFrames; s++) if (m->rendered[s][r]) (void) hipEventDestroy(m->rendered[s][r]);
-		if (m->streams[1][r] && m->streams[1][r] != m->streams[0][r]) (void) hipStreamDestroy(m->streams[1][r]);
+		for (int s = 1; s < kFrames; s++) if (m->streams[s][r] && m->streams[s][r] != m->streams[0][r]) (void) hipStreamDestroy(m->streams[s][r]);
 		if (m->streams[0][r]) (void) hipStreamDestroy(m->streams[0][r]);
 		vr_hip_destroy(m->ctx[r]);
 	}
@@ -362,8 +365,9 @@ int vr_hip_multi_prepare(vr_multi *m, uint32_t copies) {
 	return VR_OK;
 }
 
-// Queues one whole frame into `dev_rgba` on devices[0] and returns without waiting for it.  At most two frames are in flight:
-// the call first waits for the frame queued two calls ago (its band buffers are this frame's).  `consumer_stream` (a hipStream_t
+// Queues one whole frame into `dev_rgba` on devices[0] and returns without waiting for it.  At most kFrames (three) frames are in
+// flight: the call first waits for the frame queued three calls ago (its band buffers are this frame's); frames in flight must not
+// share `dev_rgba`.  `consumer_stream` (a hipStream_t
 // on devices[0], may be NULL) is made to wait for the assembled frame, so work queued on it afterwards may read `dev_rgba`.
 int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_rgba, void *consumer_stream) {
 	if (m == nullptr) return VR_ERR_INVALID;
@@ -371,7 +375,7 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 	if (p->view.width != m->width || p->view.height != m->height || m->staging[0] == nullptr)
 		return fail(m, VR_ERR_NOT_READY, "view dims differ from the window: call vr_hip_multi_set_window first");
 	const int slot = (int) (m->frames % kFrames);
-	int rc = retire(m, slot);                                // frame i-2 used this slot's buffers and events
+	int rc = retire(m, slot);                                // frame i - kFrames used this slot's buffers and events
 	if (rc) return rc;
 	const size_t slice = (size_t) m->local_rows * m->width * 4;
 	void *const *local = m->local[slot].data();
@@ -385,7 +389,7 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 		if (m->n == 1) { pr.out_rows = m->height; pr.band_rows = m->height; pr.band_stride = 1; pr.band_first = 0; }
 		else { pr.out_rows = m->local_rows; pr.band_rows = m->band_rows; pr.band_stride = (uint32_t) m->n; pr.band_first = (uint32_t) r; }
 		VRM_TRY_FRAME(m, hipSetDevice(m->dev[r]));
-		// peer-copy transport: device 0's stream read local[r] of frame i-2; this render must not overwrite it earlier.  (RCCL: the
+		// peer-copy transport: device 0's stream read local[r] of frame i - kFrames; this render must not overwrite it earlier.  (RCCL: the
 		// send ran on stream[r] itself.)  `retire` above already waited for that whole frame, so this wait is free — it keeps the
 		// ordering on the device even if the host-side wait is ever relaxed.
 		if (r > 0 && m->transport == kPeerCopy && m->frames >= (uint64_t) kFrames) VRM_TRY_FRAME(m, hipStreamWaitEvent(stream[r], m->gathered[slot], 0));
