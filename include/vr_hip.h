@@ -163,8 +163,13 @@ int vr_hip_set_tile_mapping(vr_ctx *ctx, int32_t lane_map, uint32_t phase_x, uin
  * the same parameters start their most expensive tiles first, so that a few long tiles (rays that probe along a block face, deep
  * rays next to early-terminated ones) no longer form the tail of the frame; applied only while empty-space leaping or early ray
  * termination is on (the full march has no tail).  0 = tile number = workgroup id, always.  Placement only: images are identical.
+ * 2 = as 0, and every frame leaves a COST MAP behind (profiling): vr_hip_read_tile_costs copies the last frame's tiles_x * tiles_y
+ * values — duration of the tile's workgroup, from its start to the end of its last wavefront, in units of 64 shader-clock cycles, row
+ * major from the bottom-left tile of the kernel's tile grid (32x16-pixel tiles; 32x32 on the 1024-thread paths); `host_out` NULL
+ * only reports the grid.  Waits for the context's frames.
  * No reference counterpart (its 16x16 blocks are started in grid order, GPURenderer1.cu:81-82,108). */
 int vr_hip_set_tile_scheduling(vr_ctx *ctx, uint32_t mode);
+int vr_hip_read_tile_costs(vr_ctx *ctx, uint32_t *host_out, uint32_t capacity, uint32_t *tiles_x, uint32_t *tiles_y);
 
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
@@ -176,6 +181,20 @@ int vr_hip_set_tile_scheduling(vr_ctx *ctx, uint32_t mode);
  * Return 0 ok / VR_ERR_INVALID on NULL arguments like the reference (GPURenderer1.cu:101-102). */
 int vr_hip_render(vr_ctx *ctx, const vr_params *params, uint8_t *host_rgba);
 int vr_hip_render_device(vr_ctx *ctx, const vr_params *params, void *dev_rgba, void *stream);
+
+/* What the last vr_hip_render* call of this context launched (tuning aid and test hook; no reference counterpart): the volume copy,
+ * the lane order / wave shape / tile phase that were chosen (or forced), and the kernel's tile grid. */
+typedef struct vr_launch_info {
+	uint32_t layout;        /* 0 linear array, 1 quad bricks, 2 / 3 run bricks along z / y, 4 voxel bricks, 5 oct bricks */
+	uint32_t brick_plane;   /* chunk plane of a quad copy: 0 (x,y), 1 (x,z), 2 (y,z) */
+	uint32_t lane_map;      /* (lane order) + 4 * (wave shape), as in vr_hip_set_tile_mapping */
+	uint32_t phase_x, phase_y;
+	uint32_t clamp_fetch;   /* 1: the coordinate-clamping instantiation was needed */
+	uint32_t tiles_x, tiles_y;
+	uint32_t ordered;       /* 1: the frame ran in a measured-cost tile order */
+	uint32_t straddle_permille;   /* orthogonal views along an axis: lane groups that still straddle cells under the chosen phase */
+} vr_launch_info;
+int vr_hip_last_launch(vr_ctx *ctx, vr_launch_info *out);
 
 /* ---- timing: replaces the cudaEvent pair of Profiler.cpp:46-67 ---- */
 int vr_hip_timing(vr_ctx *ctx, vr_timing *out);             /* synchronises the pending events */

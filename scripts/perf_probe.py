@@ -51,7 +51,7 @@ def main():
     samp = {"trilinear": vr.SAMPLE_TRILINEAR, "q8": vr.SAMPLE_TRILINEAR_Q8}.get(a.sampling, vr.SAMPLE_NEAREST)
     buf = torch.empty((W, W, 4), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
-    res, spread = {}, {}
+    res, spread, chosen = {}, {}, {}
     for v in [int(x) for x in a.views.split(",")]:
         p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
         for _ in range(2):                                   # builds the brick copy; records the tile costs / builds the launch order
@@ -72,9 +72,11 @@ def main():
         torch.cuda.synchronize()
         t = r.timing()
         res[v] = round(t.kernel_ms_sum / t.launches, 4)
+        li = r.last_launch()
+        chosen[v] = "L%d/p%d lanes %d shape %d phase %d,%d straddle %d" % (li["layout"], li["brick_plane"], li["lane_map"] & 3, li["lane_map"] >> 2, li["phase_x"], li["phase_y"], li["straddle_permille"])
     print(json.dumps({"volume": n, "viewport": W, "mode": a.mode, "sampling": a.sampling, "layout": a.layout, "light": a.light, "sched": a.sched,
                       "kernel_ms_per_view": res, "mean_ms": round(sum(res.values()) / len(res), 4), "minmax_ms": round(ms, 4),
-                      **({"each": spread} if a.each else {})}))
+                      "chosen": chosen, **({"each": spread} if a.each else {})}))
 
 
 if __name__ == "__main__":

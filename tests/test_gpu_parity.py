@@ -351,6 +351,14 @@ def test_tile_scheduling_is_placement_only(vr, gpu, oracle):
                 gpu.render_volume_device(p, dev.data_ptr(), other.cuda_stream)
                 other.synchronize()
                 assert np.array_equal(dev.cpu().numpy(), want), (view_i, samp)
+                # mode 2: workgroup order + the cost map of the frame (profiling): same image, one cost per tile of the kernel's grid
+                gpu.set_tile_scheduling(2)
+                assert np.array_equal(gpu.render_volume(p), want), (view_i, samp)
+                info, costs = gpu.last_launch(), gpu.tile_costs()
+                assert costs.shape == (info["tiles_y"], info["tiles_x"]) and info["ordered"] == 0
+                assert info["tiles_x"] >= (W + 31) // 32 and info["tiles_y"] >= (H + 15) // 16
+                assert (costs[: H // 16, : W // 32] > 0).all()          # every tile that lies inside the frame ran and was timed
+                assert info["layout"] in (1, 2, 3, 4) and info["lane_map"] < 12 and info["phase_x"] < 8 and info["phase_y"] < 8
     finally:
         gpu.set_tile_scheduling(1)
 

@@ -58,6 +58,11 @@ class VrTiming(C.Structure):
                 ("kernel_ms_max", C.c_float), ("total_ms_max", C.c_float)]
 
 
+class VrLaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("layout", "brick_plane", "lane_map", "phase_x", "phase_y", "clamp_fetch", "tiles_x", "tiles_y",
+                                          "ordered", "straddle_permille")]
+
+
 def library_path():
     """In-tree libvr_hip.so; VR_HIP_LIB selects another build of the same library (A/B runs of kernel variants)."""
     return os.environ.get("VR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvr_hip.so")
@@ -97,6 +102,8 @@ def lib():
         "vr_hip_set_tile_mapping": (C.c_int, [vp, C.c_int32, u32, u32]),
         "vr_hip_set_brick_plane": (C.c_int, [vp, C.c_int32]),
         "vr_hip_set_tile_scheduling": (C.c_int, [vp, u32]),
+        "vr_hip_last_launch": (C.c_int, [vp, P(VrLaunchInfo)]),
+        "vr_hip_read_tile_costs": (C.c_int, [vp, vp, u32, P(u32), P(u32)]),
         "vr_hip_render": (C.c_int, [vp, P(VrParams), vp]),
         "vr_hip_render_device": (C.c_int, [vp, P(VrParams), vp, vp]),
         "vr_hip_timing": (C.c_int, [vp, P(VrTiming)]),

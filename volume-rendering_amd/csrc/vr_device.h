@@ -66,6 +66,26 @@ struct RayKernelArgs {
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 };
+// Tiles are numbered in VR_TILE_ORDER x VR_TILE_ORDER blocks (blocks row-major, tiles row-major inside a block, the ragged right /
+// bottom margins after them): consecutive workgroups — which the hardware spreads over the eight XCDs — are screen neighbours.
+#ifndef VR_TILE_ORDER
+#define VR_TILE_ORDER 8
+#endif
+// tile number -> tile column / row; what raymarch_kernel computes (without its experiment switches), for the host (cost map)
+inline void tile_number_to_xy(uint32_t tile, uint32_t tiles_x, uint32_t tiles_y, uint32_t *x, uint32_t *y) {
+	constexpr uint32_t B = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
+	const uint32_t full_cols = tiles_x / B, full_rows = tiles_y / B, nblocked = full_cols * full_rows * B * B;
+	if (tile < nblocked) {
+		const uint32_t blk = tile / (B * B), in = tile - blk * (B * B), by = blk / full_cols, bx = blk - by * full_cols;
+		*x = bx * B + in % B; *y = by * B + in / B;
+		return;
+	}
+	uint32_t rest = tile - nblocked;
+	const uint32_t right_w = tiles_x - full_cols * B, right_n = right_w * full_rows * B;
+	if (rest < right_n) { *y = rest / right_w; *x = full_cols * B + rest % right_w; }
+	else { rest -= right_n; *y = full_rows * B + rest / tiles_x; *x = rest % tiles_x; }
+}
+
 // measured-cost launch order of a frame (vr_kernels.hip tile_order_kernel): order = workgroup id -> tile number or NULL (identity);
 // cost = per tile, the longest wave of the tile in 64-cycle units, or NULL (not recorded)
 struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr; };

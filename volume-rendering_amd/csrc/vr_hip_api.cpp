@@ -69,7 +69,10 @@ struct vr_ctx {
 	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0, order_state = 0, order_layout = 0;
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
-	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order
+	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order, 2 = cost map
+	vr_launch_info last_launch = {};        // vr_hip_last_launch
+	uint32_t *cost_map = nullptr;           // mode 2: what every tile of the LAST frame cost (vr_hip_read_tile_costs)
+	uint32_t cost_map_capacity = 0, cost_map_tiles_x = 0, cost_map_tiles_y = 0;
 	bool oct_always = false;                // vr_hip_set_brick_plane(5): 2-byte voxels read the oct bricks for every view (testing)
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
@@ -205,7 +208,7 @@ uint32_t choose_tile_mapping(RayKernelArgs &a) {
 	// edges that are not 4-cell (128-byte line) boundaries — a wave whose 4x4 cells sit inside one line column touches a
 	// quarter of the lines, and workgroup footprints that end on line boundaries do not fetch their border lines twice
 	// (measured before: 2.0x the compulsory bytes at L2 with 4-pixel alignment only).
-	long groups_seen = 0, groups_straddling = 0;          // of the winning phases, both screen directions
+	long groups_seen[2] = { 0, 0 }, groups_straddling[2] = { 0, 0 };      // of the winning phase, per screen direction (0 = x, 1 = y)
 	auto best_phase = [&](bool horizontal, uint32_t first, uint32_t count, uint32_t other_centre) {
 		const float *sdir = horizontal ? sx : sy;
 		const int ax = major(sdir);
@@ -234,15 +237,24 @@ uint32_t choose_tile_mapping(RayKernelArgs &a) {
 			}
 			if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ph; best_seen = seen; best_bad = bad; }
 		}
-		groups_seen += best_seen; groups_straddling += best_bad;
+		groups_seen[horizontal ? 0 : 1] = best_seen; groups_straddling[horizontal ? 0 : 1] = best_bad;
 		return best;
 	};
 	// rows: local row ly maps to frame row gy; with bands of a multiple of 8 rows (or one band) gy = ly + const (mod 8)
 	const uint32_t gy0 = a.p.band_first * a.p.band_rows;
 	a.phase_x = best_phase(true, a.p.x0, a.p.out_width, gy0 + std::min(a.p.out_rows, a.p.band_rows) / 2u);
 	a.phase_y = best_phase(false, gy0, a.p.out_rows < a.p.band_rows ? a.p.out_rows : a.p.band_rows, a.p.x0 + a.p.out_width / 2u);
-	if (!axis_aligned || groups_seen == 0) return 1000u;
-	return (uint32_t) (groups_straddling * 1000 / groups_seen);
+	if (!axis_aligned || groups_seen[0] + groups_seen[1] == 0) return 1000u;
+	// One screen direction clean, the other not (pose (90,0,0): the rows of pixels sit on cell boundaries of the axis that carries the
+	// 4e-8 of rounding noise, 9 % of the 2x2 blocks straddle; the columns are clean): TRILINEAR puts the four lanes of a quad along the
+	// CLEAN direction — measured on that pose 2.49 -> 2.24 ms (scripts/phase_grid_probe.py); with both directions clean the 2x2 blocks
+	// stay (2.11 against 2.16 ms on pose (0,0,0)).  What is returned is the share of straddling groups of the lane order chosen.
+	if (!nearest && groups_seen[0] > 0 && groups_seen[1] > 0) {
+		const bool dirty_x = groups_straddling[0] * 50 > groups_seen[0], dirty_y = groups_straddling[1] * 50 > groups_seen[1];     // > 2 %
+		if (dirty_y && !dirty_x) { a.lane_map = kLaneRows; return (uint32_t) (groups_straddling[0] * 1000 / groups_seen[0]); }
+		if (dirty_x && !dirty_y) { a.lane_map = kLaneColumns; return (uint32_t) (groups_straddling[1] * 1000 / groups_seen[1]); }
+	}
+	return (uint32_t) ((groups_straddling[0] + groups_straddling[1]) * 1000 / (groups_seen[0] + groups_seen[1]));
 }
 
 int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
@@ -454,6 +466,22 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		}
 	}
 
+	if (c->tile_scheduling == 2 && ntiles <= (1u << 20)) {     // profiling: the cost of every tile of this frame, tile = workgroup id
+		if (c->cost_map_capacity < ntiles) {
+			VR_TRY(c, drain(c));
+			if (c->cost_map) (void) hipFree(c->cost_map);
+			c->cost_map = nullptr; c->cost_map_capacity = 0;
+			VR_TRY(c, hipMalloc((void **) &c->cost_map, (size_t) ntiles * 4));
+			c->cost_map_capacity = ntiles;
+		}
+		VR_TRY(c, hipMemsetAsync(c->cost_map, 0, (size_t) ntiles * 4, stream));
+		sched.cost = c->cost_map;
+		c->cost_map_tiles_x = plan.tiles_x; c->cost_map_tiles_y = plan.tiles_y;
+	}
+
+	c->last_launch = vr_launch_info{ a.layout, a.brick_plane, a.lane_map, a.phase_x, a.phase_y, a.clamp_fetch, plan.tiles_x, plan.tiles_y,
+	                                 sched.order != nullptr ? 1u : 0u, hit != nullptr ? hit->straddle_permille : 1000u };
+
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
@@ -613,6 +641,7 @@ void vr_hip_destroy(vr_ctx *c) {
 	}
 	if (c->aux_start) (void) hipEventDestroy(c->aux_start);
 	if (c->aux_stop) (void) hipEventDestroy(c->aux_stop);
+	if (c->cost_map) (void) hipFree(c->cost_map);
 	for (auto &e : c->map_cache) { if (e.cost) (void) hipFree(e.cost); if (e.order) (void) hipFree(e.order); if (e.order_ready) (void) hipEventDestroy(e.order_ready); }
 	if (c->fb) (void) hipFree(c->fb);
 	if (c->tf) (void) hipFree(c->tf);
@@ -726,9 +755,35 @@ int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 
 int vr_hip_set_tile_scheduling(vr_ctx *c, uint32_t mode) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	if (mode > 1u) return fail(c, VR_ERR_INVALID, "tile scheduling mode must be 0 (workgroup id) or 1 (measured-cost order)");
+	if (mode > 2u) return fail(c, VR_ERR_INVALID, "tile scheduling mode must be 0 (workgroup id), 1 (measured-cost order) or 2 (workgroup id + cost map)");
 	c->tile_scheduling = mode;
 	for (auto &e : c->map_cache) e.order_state = 0;
+	return VR_OK;
+}
+
+int vr_hip_last_launch(vr_ctx *c, vr_launch_info *out) {
+	if (c == nullptr || out == nullptr) return VR_ERR_INVALID;
+	*out = c->last_launch;
+	return VR_OK;
+}
+
+int vr_hip_read_tile_costs(vr_ctx *c, uint32_t *host_out, uint32_t capacity, uint32_t *tiles_x, uint32_t *tiles_y) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (tiles_x) *tiles_x = c->cost_map_tiles_x;
+	if (tiles_y) *tiles_y = c->cost_map_tiles_y;
+	const uint32_t n = c->cost_map_tiles_x * c->cost_map_tiles_y;
+	if (c->cost_map == nullptr || n == 0) return fail(c, VR_ERR_NOT_READY, "no cost map: render a frame with vr_hip_set_tile_scheduling(ctx, 2) first");
+	if (host_out == nullptr) return VR_OK;                   // size query
+	if (capacity < n) return fail(c, VR_ERR_INVALID, "cost map buffer too small");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, drain(c));
+	std::vector<uint32_t> by_number(n);
+	VR_TRY(c, hipMemcpy(by_number.data(), c->cost_map, (size_t) n * 4, hipMemcpyDeviceToHost));
+	for (uint32_t t = 0; t < n; t++) {                        // tile number (blocks of tiles) -> row-major
+		uint32_t x = 0, y = 0;
+		tile_number_to_xy(t, c->cost_map_tiles_x, c->cost_map_tiles_y, &x, &y);
+		host_out[(size_t) y * c->cost_map_tiles_x + x] = by_number[t];
+	}
 	return VR_OK;
 }
 

@@ -550,9 +550,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	//    Concentrating a compact brick region on ONE L2 (1, 2) is markedly slower than letting all eight L2s serve it —
 	//    the reuse between neighbouring tiles is small (the quad elements already carry the +1 neighbours) and a compact
 	//    region exercises few L2 channels — so the plain interleave (0) is the default.  Placement affects speed only.
-#ifndef VR_TILE_ORDER
-#define VR_TILE_ORDER 8
-#endif
 #ifndef VR_XCD_MODE
 #define VR_XCD_MODE 0
 #endif

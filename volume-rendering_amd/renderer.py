@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from .binding import VrError, VrParams, VrTiming, lib
+from .binding import VrError, VrLaunchInfo, VrParams, VrTiming, lib
 
 
 class HipRenderer:
@@ -85,6 +85,21 @@ class HipRenderer:
     def set_tile_scheduling(self, mode=1):
         """0: tile = workgroup id; 1 (default): measured-cost order for frames with ESL / ERT on (most expensive tiles first); speed only."""
         self._check(self._L.vr_hip_set_tile_scheduling(self._ctx, int(mode)), "set_tile_scheduling")
+
+    def last_launch(self):
+        """What the last render launched: dict(layout, brick_plane, lane_map, phase_x, phase_y, clamp_fetch, tiles_x, tiles_y, ordered, straddle_permille)."""
+        info = VrLaunchInfo()
+        self._check(self._L.vr_hip_last_launch(self._ctx, C.byref(info)), "last_launch")
+        return {n: int(getattr(info, n)) for n, _ in VrLaunchInfo._fields_}
+
+    def tile_costs(self):
+        """Cost map of the last frame rendered with set_tile_scheduling(2): [tiles_y, tiles_x] uint32, 64-cycle units per workgroup tile."""
+        import numpy as np
+        tx, ty = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.vr_hip_read_tile_costs(self._ctx, None, 0, C.byref(tx), C.byref(ty)), "read_tile_costs")
+        out = np.zeros((ty.value, tx.value), dtype=np.uint32)
+        self._check(self._L.vr_hip_read_tile_costs(self._ctx, out.ctypes.data, out.size, C.byref(tx), C.byref(ty)), "read_tile_costs")
+        return out
 
     def generate_volume(self, kind, n, seed=1, bytes_per_voxel=1):
         """Synthetic benchmark volume ('shell' | 'noise') generated straight into HBM."""
