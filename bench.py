@@ -340,11 +340,14 @@ def run_rank(a):
             torch.cuda.synchronize()
 
     def timed_region():
-        # set-up, not a step: one frame per view, so that the brick copy each view reads exists (copies are built by the first frame
-        # that wants them) and has been touched once, whatever --warmup is
+        # set-up, not a step: four frames per view, whatever --warmup is — the first builds the brick copy the view reads (copies are
+        # built by the first frame that wants them) and touches it once; a view that is not along a volume axis reads BOTH run copies,
+        # chosen per screen tile by measurement: its frames 0-3 run on one copy each, the last two recording what every tile cost
+        # (vr_hip_set_brick_plane in include/vr_hip.h; the measured-cost tile order of the other modes takes two frames the same way)
         if not a.dry_run:
-            for i in range(8):
-                render(i, 0)
+            for _ in range(4):
+                for i in range(8):
+                    render(i, 0)
             torch.cuda.synchronize()
         for i in range(a.warmup):
             step(i)
@@ -475,6 +478,8 @@ def run_rank(a):
             if legs:
                 out["extras"] = extras(vr, r, scene, views, split, local[0], stream, render_stream, n, W, H, bpv) if "modes" in legs else {}
                 set_mode(scene, a.mode)
+                if "modes" in legs:      # before the legs that create many streams: a process has 8 hardware queues, later streams share them
+                    out["extras"]["two_frames_concurrent"] = bx.concurrent_frames_leg(vr, r, params, local[0])
                 with torch.cuda.stream(render_stream):
                     if "host" in legs:
                         out["extras"]["host_buffer"] = bx.host_buffer_leg(vr, r, scene, views, sampling)
@@ -504,9 +509,6 @@ def run_rank(a):
                                                           "4 two-voxel loads per sample — north_star's literal layout, timed beside the product's brick copies"}
                 if "multi" in legs:
                     out["extras"]["multi_overhead"] = bx.multi_overhead(vr, local_rank)
-                if "modes" in legs:
-                    set_mode(scene, a.mode)
-                    out["extras"]["two_frames_concurrent"] = bx.concurrent_frames_leg(vr, r, params, local[0])
             if world == 1 and not a.no_cpu_baseline and bpv == 1:
                 out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
                 # the comparison north_star asks for, labelled — vs_baseline itself stays null (BASELINE.md has no published number)
@@ -546,7 +548,7 @@ def extras(vr, r, scene, views, split, buf, stream, render_stream, n, W, H, bpv=
                               ("ertonly_nearest", "ertonly", vr.SAMPLE_NEAREST)):
         set_mode(scene, mode)
         ps = [split.apply(scene.frame_params(v, samp)) for v in views]
-        for _ in range(2):                          # builds the copies these views read; records / builds the measured-cost tile order
+        for _ in range(4):                          # builds the copies these views read; records / builds the measured-cost tile order
             for p in ps:
                 r.render_volume_device(p, buf.data_ptr(), stream)
         render_stream.synchronize()

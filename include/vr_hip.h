@@ -148,7 +148,11 @@ int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
  * else (x,y)); 3 / 4 = the "run bricks", copies in which the two slices of a sample along z / along y are 8 adjacent bytes (one
  * gather per sample), which per-view selection uses for every view whose lane quads cannot be chunk-aligned; 5 = 2-byte volumes read
  * their oct bricks (one 16-byte element per cell) for EVERY view — per-view selection uses them for orthogonal views with at most
- * one cell per pixel and the quad bricks otherwise.  Speed only; testing and tuning aid.  No reference counterpart. */
+ * one cell per pixel and the quad bricks otherwise; 6 = BOTH run copies in one launch, chosen per screen tile — what per-view
+ * selection does for full-march frames of views that are not along a volume axis: which copy is cheaper depends on the cube face
+ * a tile's rays enter through, so frames 0 - 3 of a parameter set run on one copy each (twice, the second time recording what every
+ * tile cost) and from frame 4 on every tile reads the copy that was cheaper for it — here for every view; 7 = both copies on
+ * alternating tiles (no measurement; parity tests).  Speed only; testing and tuning aid.  No reference counterpart. */
 int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
 /* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
@@ -185,7 +189,7 @@ int vr_hip_render_device(vr_ctx *ctx, const vr_params *params, void *dev_rgba, v
 /* What the last vr_hip_render* call of this context launched (tuning aid and test hook; no reference counterpart): the volume copy,
  * the lane order / wave shape / tile phase that were chosen (or forced), and the kernel's tile grid. */
 typedef struct vr_launch_info {
-	uint32_t layout;        /* 0 linear array, 1 quad bricks, 2 / 3 run bricks along z / y, 4 voxel bricks, 5 oct bricks */
+	uint32_t layout;        /* 0 linear array, 1 quad bricks, 2 / 3 run bricks along z / y, 4 voxel bricks, 5 oct bricks, 6 both run copies (per tile) */
 	uint32_t brick_plane;   /* chunk plane of a quad copy: 0 (x,y), 1 (x,z), 2 (y,z) */
 	uint32_t lane_map;      /* (lane order) + 4 * (wave shape), as in vr_hip_set_tile_mapping */
 	uint32_t phase_x, phase_y;

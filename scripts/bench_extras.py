@@ -21,9 +21,10 @@ def set_mode(scene, mode):
         scene.set_modes(esl=True, ray_threshold=0.95)
 
 
-def time_views(r, params, buf, stream, sync, warm=2, reps=3):
+def time_views(r, params, buf, stream, sync, warm=4, reps=3):
     """hipEvent kernel time of `reps` launches per parameter set after `warm` untimed ones (the first builds the brick copy the
-    view reads, the first two record / build the measured-cost tile order): per-view mean, overall mean and max."""
+    view reads, the first two record / build the measured-cost tile order, the first four the per-tile copy choice of the views
+    that are not along an axis): per-view mean, overall mean and max."""
     per_view, worst = [], 0.0
     for p in params:
         for _ in range(warm):

@@ -54,7 +54,7 @@ def main():
     res, spread, chosen = {}, {}, {}
     for v in [int(x) for x in a.views.split(",")]:
         p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
-        for _ in range(2):                                   # builds the brick copy; records the tile costs / builds the launch order
+        for _ in range(4):                                   # builds the brick copy; records the tile costs / builds the launch order or the per-tile copy choice
             r.render_volume_device(p, buf.data_ptr(), stream)
         torch.cuda.synchronize()
         r.timing_reset()

@@ -150,6 +150,23 @@ def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
             for plane in (-1, 0, 1, 2, 3, 4):    # brick copy per view, then each chunk plane and both run-brick copies forced (vr_hip_set_brick_plane)
                 gpu.set_brick_plane(plane)
                 assert np.array_equal(gpu.render_volume(p), ref), (name, label, plane)
+            # both run copies in ONE launch, per tile (full-march frames only): 7 = alternating tiles, 6 = measured — frames 0-3 run on
+            # one copy each (2 and 3 record the tile costs), frames 4 and 5 read the per-tile choice; fp32 and 8-bit weights, lit and unlit
+            for samp in (vr.SAMPLE_TRILINEAR, vr.SAMPLE_TRILINEAR_Q8):
+                for kd in (0.6, 0.0):
+                    pf = golden.params(case, samp)
+                    pf.esl, pf.ray_threshold, pf.light_kd = 0, 1.0, kd
+                    want = oracle.render(pf, golden.voxels(name), st["tf"], st["esl"])
+                    gpu.set_brick_plane(7)
+                    assert np.array_equal(gpu.render_volume(pf), want), (name, label, samp, kd, "alternating tiles")
+                    clamped = gpu.last_launch()["clamp_fetch"] != 0      # the clamping instantiation never takes the per-tile choice
+                    assert gpu.last_launch()["layout"] == (2 if clamped else 6) or gpu.last_launch()["layout"] == 3
+                    gpu.set_brick_plane(6)
+                    seen = []
+                    for frame in range(6):
+                        assert np.array_equal(gpu.render_volume(pf), want), (name, label, samp, kd, "measured", frame)
+                        seen.append(gpu.last_launch()["layout"])
+                    assert clamped or seen == [2, 3, 2, 3, 6, 6], seen
             gpu.set_brick_plane(-1)
 
 

@@ -65,6 +65,7 @@ struct RayKernelArgs {
 	uint32_t brick_plane;              // chunk plane of the brick copy handed to the kernel (kPlaneXY ...)
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
+	uint64_t alt_copy;                 // kLayoutRunDual: address of the run copy along y (the kernel's `vol` argument is the copy along z)
 };
 // Tiles are numbered in VR_TILE_ORDER x VR_TILE_ORDER blocks (blocks row-major, tiles row-major inside a block, the ragged right /
 // bottom margins after them): consecutive workgroups — which the hardware spreads over the eight XCDs — are screen neighbours.
@@ -124,8 +125,15 @@ struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr;
 //                   (6.7-10 ns per wave in every lane pattern), and the quad bricks need two of those per sample.  Twice the bytes of
 //                   the quad copy (16 per voxel: 128 GiB for 2048^3); for 1-byte voxels the same idea (8-byte octets) lost against
 //                   the run bricks, which share their elements along z.
-enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5 };
-__host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY; }
+//   kLayoutRunDual: BOTH run copies in one launch, chosen per screen tile (bit 31 of the tile's entry in the launch order: 0 = runs
+//                   along z, 1 = runs along y).  For a view that is not along an axis the better copy depends on the cube face a tile's
+//                   rays enter through: all lanes of a wave start ON that face and march in lockstep, so the wave's 64 samples lie in a
+//                   plane parallel to it — with runs perpendicular to that plane no two lanes share a run (measured per tile on the
+//                   oblique benchmark pose: the upper half of the screen is 25 % cheaper with runs along y, the lower half with runs
+//                   along z).  The host measures both copies per tile on the first two frames of a parameter set (vr_hip_api.cpp).
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5, kLayoutRunDual = 6 };
+__host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY || layout == (int) kLayoutRunDual; }
+constexpr uint32_t kTileAltBit = 0x80000000u;       // kLayoutRunDual: set in a launch-order entry = this tile reads the copy with runs along y
 __host__ __device__ constexpr bool is_brick_table_layout(int layout) { return layout == (int) kLayoutBricked || layout == (int) kLayoutVoxel; }
 constexpr uint32_t kRunLen = 9, kRunBytes = kRunLen * 4, kRunBrickBytes = 64 * kRunBytes;       // 8x8 cell columns per brick
 // byte offset of cell column (x & 7, y & 7) inside a run brick: 2-D Morton order, 36-byte runs
@@ -202,6 +210,8 @@ struct RaymarchPlan { bool reads_linear; uint32_t tiles_x, tiles_y; };
 RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t bytes_per_voxel);
 // cost[ntiles] (recorded by a frame) -> order[ntiles] for the next frame with the same parameters; clears cost
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t ntiles, hipStream_t stream);
+// kLayoutRunDual: choice[t] = t | (cost_y[t] < cost_z[t] ? kTileAltBit : 0); both costs NULL = alternating tiles (testing)
+hipError_t launch_tile_choice(const uint32_t *cost_z, const uint32_t *cost_y, uint32_t *choice, uint32_t ntiles, hipStream_t stream);
 
 hipError_t launch_minmax(const void *volume, uint32_t bytes_per_voxel, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                          uint32_t esl_block_dims, uint8_t *minmax_dev /* 32768 x {min,max} */, hipStream_t stream);

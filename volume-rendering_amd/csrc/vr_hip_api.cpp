@@ -67,6 +67,11 @@ struct vr_ctx {
 	// tiles look expensive) and rebuilds the order behind itself; state 2 is final.
 	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille;
 	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0, order_state = 0, order_layout = 0;
+	                  // kLayoutRunDual (full-march frames of views that are not along an axis; such frames never use a cost order, so the
+	                  // buffers above are free): frames 0 / 1 of the parameter set run on the copy along z / along y (first touch of each),
+	                  // frames 2 / 3 do so again and record their tile costs (cost[] / second half of order[]), the choice kernel behind
+	                  // frame 3 fills the first half of order[], and from frame 4 on the tiles read the copy that was cheaper for them
+	                  uint32_t dual_state = 0;
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
 	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order, 2 = cost map
@@ -312,7 +317,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	a.force_wide = c->force_wide;
 	const bool bricked = c->layout == VR_LAYOUT_BRICKED;
 	a.layout = bricked ? kLayoutBricked : kLayoutLinear;
-	bool run_candidate = false, run_if_unaligned = false;
+	bool run_candidate = false, run_if_unaligned = false, dual_candidate = false;
 	uint32_t run_layout = kLayoutRun;        // which run copy a run-brick frame reads: runs along z unless the view marches along z
 	// Which brick copy: the one whose 16-byte chunks lie in the plane perpendicular to the view's dominant axis, so that the
 	// pixels of a lane quad — neighbours on the screen — are neighbours inside a chunk (TRILINEAR; NEAREST keeps (x,y)).
@@ -338,8 +343,13 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 				else if (!p->view.perspective) run_if_unaligned = true;
 			} else {
 				run_candidate = true;       // not along an axis: lane quads straddle chunks whatever the plane -> one 8-byte gather
+				// ... and which run copy is better depends on the cube face a tile's rays enter through (kLayoutRunDual).  Orthogonal
+				// views only: on the oblique perspective pose the two copies are level almost everywhere (per-tile best of both -3 %)
+				// and mixing them costs that much again (2.60 -> 2.62-2.64 ms); on the orthogonal one 3.20 -> 2.81 ms.
+				dual_candidate = !p->view.perspective;
 			}
 		}
+		if (plane == kPlanes + 3 || plane == kPlanes + 4) { run_candidate = true; dual_candidate = true; }     // forced: 6 = measured per-tile choice, 7 = alternating tiles
 		if (plane < kPlanes && copy_possible(c, kCopyQuadXY + plane)) a.brick_plane = plane;
 		else if (plane == kPlanes && copy_possible(c, kCopyRunZ)) a.layout = kLayoutRun;               // forced: 3 = runs along z, 4 = runs along y
 		else if (plane == kPlanes + 1 && copy_possible(c, kCopyRunY)) a.layout = kLayoutRunY;
@@ -380,6 +390,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			hit = &c->map_cache[c->map_next];
 			hit->straddle_permille = straddle;
 			hit->order_state = 0;                        // the recycled entry's launch order belonged to other parameters
+			hit->dual_state = 0; hit->order_tiles = 0;
 			c->map_next = (c->map_next + 1) % 16u;
 			if (c->map_cached < 16u) c->map_cached++;
 			hit->p = *p; memcpy(hit->dim, c->dim, sizeof c->dim);
@@ -391,10 +402,25 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		// differently across the frame: no phase aligns it.  Measured on that pose: 3.18 ms with the run bricks against 3.71 ms.
 		if (run_if_unaligned && hit->straddle_permille > 150u && copy_possible(c, run_layout == kLayoutRunY ? kCopyRunY : kCopyRunZ)) a.layout = run_layout;
 	}
+	// Per-tile choice between the two run copies (kLayoutRunDual, vr_device.h): full-march frames only (with leaping or early
+	// termination the rays are short and the tile order above is what matters), automatic tile mapping only, never for the clamping
+	// instantiation (its clamp bounds are per axis, and the tile's y / z exchange would have to reach them).
+	int dual_stage = -1;                                 // -1: not a dual frame; 0..3: the four frames before; 4: per-tile choice in use
+	const bool dual_test = c->brick_plane_force == (int) kPlanes + 4;
+	if (dual_candidate && hit != nullptr && is_run_layout(a.layout) && c->tile_scheduling == 1 && !VR_ORDER_ALWAYS && !p->esl && p->ray_threshold >= 1.0f &&
+	    !a.clamp_fetch && c->bpv == 1 && copy_possible(c, kCopyRunZ) && copy_possible(c, kCopyRunY)) {
+		dual_stage = dual_test ? 4 : (int) hit->dual_state;
+		a.layout = dual_stage == 4 ? kLayoutRunDual : ((dual_stage & 1) ? kLayoutRunY : kLayoutRun);
+	}
 	// The copy this frame reads, built now if this is its first use.  A build that is refused (HBM guard, allocation, linear array
 	// released) degrades to the next best resident copy; the image is the same.
 	const void *brick_copy = nullptr;
-	if (a.layout != kLayoutLinear) {
+	if (a.layout == kLayoutRunDual) {
+		brick_copy = copy_for(c, kCopyRunZ);
+		a.alt_copy = (uint64_t) (uintptr_t) copy_for(c, kCopyRunY);
+		if (brick_copy == nullptr || a.alt_copy == 0) { a.layout = run_layout; dual_stage = -1; brick_copy = nullptr; }
+	}
+	if (a.layout != kLayoutLinear && brick_copy == nullptr) {
 		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
 		                      a.layout == kLayoutOct ? kCopyOct : kCopyQuadXY + a.brick_plane;
 		brick_copy = copy_for(c, want);
@@ -466,6 +492,38 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		}
 	}
 
+	// kLayoutRunDual: frames 2 and 3 record, frame 3 is followed by the choice kernel, frame 4 onwards reads the choice.  Every step
+	// is ordered behind the one before through the entry's event when it runs on another stream.
+	bool dual_advance = false;
+	if (dual_stage >= 0) {
+		if (ntiles < 2u || ntiles > (1u << 20)) dual_stage = -1;      // (a frame that keeps kLayoutRunDual without a choice reads the copy along z)
+		else if (hit->capacity < ntiles) {
+			if (hit->cost) { VR_TRY(c, drain(c)); (void) hipFree(hit->cost); (void) hipFree(hit->order); hit->cost = hit->order = nullptr; hit->capacity = 0; }
+			if (hipMalloc((void **) &hit->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &hit->order, (size_t) ntiles * 8) == hipSuccess) hit->capacity = ntiles;
+			else { (void) hipGetLastError(); if (hit->cost) (void) hipFree(hit->cost); hit->cost = hit->order = nullptr; dual_stage = -1; }
+			if (!dual_test) { hit->dual_state = 0; if (dual_stage > 0) dual_stage = -1; }      // (cannot happen: the grid of a parameter set does not change)
+		}
+	}
+	if (dual_stage >= 0) {
+		if (hit->order_ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&hit->order_ready, hipEventDisableTiming));
+		if (dual_stage > 0 && !(dual_test && hit->order_tiles != ntiles) && hit->order_stream != nullptr && stream != hit->order_stream)
+			VR_TRY(c, hipStreamWaitEvent(stream, hit->order_ready, 0));
+		if (dual_test) {                                   // alternating tiles, built once per grid size
+			if (hit->order_tiles != ntiles) {
+				VR_TRY(c, launch_tile_choice(nullptr, nullptr, hit->order, ntiles, stream));
+				VR_TRY(c, hipEventRecord(hit->order_ready, stream));
+				hit->order_tiles = ntiles; hit->order_stream = stream;
+			}
+			sched.order = hit->order;
+		} else if (dual_stage == 2 || dual_stage == 3) {
+			uint32_t *into = dual_stage == 2 ? hit->cost : hit->order + hit->capacity;
+			VR_TRY(c, hipMemsetAsync(into, 0, (size_t) ntiles * 4, stream));
+			sched.cost = into;
+			dual_advance = true;
+		} else if (dual_stage == 4) sched.order = hit->order;
+		else dual_advance = true;
+	}
+
 	if (c->tile_scheduling == 2 && ntiles <= (1u << 20)) {     // profiling: the cost of every tile of this frame, tile = workgroup id
 		if (c->cost_map_capacity < ntiles) {
 			VR_TRY(c, drain(c));
@@ -489,6 +547,12 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	VR_TRY(c, launch_raymarch(a, c->vol, brick_copy, c->bpv, c->tf, c->esl, dev_rgba, sched, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
+	if (dual_advance) {                          // behind the frame, on its stream
+		if (dual_stage == 3) VR_TRY(c, launch_tile_choice(hit->cost, hit->order + hit->capacity, hit->order, ntiles, stream));
+		VR_TRY(c, hipEventRecord(hit->order_ready, stream));
+		hit->order_stream = stream; hit->order_tiles = ntiles;
+		hit->dual_state = (uint32_t) dual_stage + 1u;
+	}
 	if (record) {                                // behind the frame, on its stream: the next frame with these parameters is ordered
 		VR_TRY(c, launch_tile_order(hit->cost, hit->order + (hit->order_state == 0 ? 0u : hit->capacity), ntiles, stream));
 		if (hit->order_ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&hit->order_ready, hipEventDisableTiming));
@@ -746,7 +810,9 @@ int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 
 int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (c == nullptr) return VR_ERR_INVALID;
-	if (plane < -1 || plane > (int32_t) kPlanes + 2) return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z), 4 (run bricks along y) or 5 (oct bricks for every view of a 2-byte volume)");
+	if (plane < -1 || plane > (int32_t) kPlanes + 4)
+		return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z), 4 (run bricks along y), 5 (oct bricks for every view of a "
+		                               "2-byte volume), 6 (both run copies, chosen per tile by measurement, for every full-march view) or 7 (both run copies on alternating tiles)");
 	c->oct_always = plane == (int32_t) kPlanes + 2;
 	c->brick_plane_force = c->oct_always ? -1 : plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane
@@ -757,7 +823,7 @@ int vr_hip_set_tile_scheduling(vr_ctx *c, uint32_t mode) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (mode > 2u) return fail(c, VR_ERR_INVALID, "tile scheduling mode must be 0 (workgroup id), 1 (measured-cost order) or 2 (workgroup id + cost map)");
 	c->tile_scheduling = mode;
-	for (auto &e : c->map_cache) e.order_state = 0;
+	for (auto &e : c->map_cache) { e.order_state = 0; e.dual_state = 0; e.order_tiles = 0; }
 	return VR_OK;
 }
 

@@ -304,8 +304,9 @@ template <bool Q8> __device__ __forceinline__ float filter_weight(float w) {
 
 // (xb, yb, zb): the texel-space coordinates the words were fetched at; the fetch slots of the march do not carry them — the few
 // samples that get this far recompute them from the sample's k (three fused multiply-adds, the same values bit for bit)
+// `along_y` (wave-uniform, kLayoutRunDual only): the words came from the copy with runs along y
 template <int BPV, int LAYOUT, bool Q8>
-__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a, float xb, float yb, float zb) {
+__device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, const RayKernelArgs &a, float xb, float yb, float zb, bool along_y = false) {
 	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x)));
 	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y)));
 	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z)));
@@ -313,6 +314,10 @@ __device__ __forceinline__ float tri_resolve(const TriFetch<BPV, LAYOUT> &f, con
 	if (LAYOUT == kLayoutRunY) {                         // elements are (x,z) neighbourhoods, the two words are rows y and y+1
 		v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v001 = (float) ((f.w0 >> 16) & 0xffu); v101 = (float) (f.w0 >> 24);
 		v010 = (float) (f.w1 & 0xffu); v110 = (float) ((f.w1 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
+	} else if (LAYOUT == kLayoutRunDual) {               // either of the two: bytes 2, 3 of word 0 and bytes 0, 1 of word 1 change places
+		const float t2 = (float) ((f.w0 >> 16) & 0xffu), t3 = (float) (f.w0 >> 24), t4 = (float) (f.w1 & 0xffu), t5 = (float) ((f.w1 >> 8) & 0xffu);
+		v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v011 = (float) ((f.w1 >> 16) & 0xffu); v111 = (float) (f.w1 >> 24);
+		v010 = along_y ? t4 : t2; v110 = along_y ? t5 : t3; v001 = along_y ? t2 : t4; v101 = along_y ? t3 : t5;
 	} else if (LAYOUT != kLayoutLinear) {
 		if (BPV == 1) {                                  // v_cvt_f32_ubyte0..3
 			v000 = (float) (f.w0 & 0xffu); v100 = (float) ((f.w0 >> 8) & 0xffu); v010 = (float) ((f.w0 >> 16) & 0xffu); v110 = (float) (f.w0 >> 24);
@@ -473,10 +478,14 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	// hardware slot, HW_ID, was tried and is WRONG: a wave that is context-switched out and back — several queues share the GPU —
 	// comes back in another slot, reads a record nobody wrote, and the atomic below goes to a wild address.)
 	__shared__ uint32_t group_sched[4];
-	const uint32_t tile_of_group = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
+	const uint32_t order_entry = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
+	// kLayoutRunDual: bit 31 of the entry selects the tile's copy (runs along y instead of z); it waits in LDS like the rest of the record
+	const uint32_t tile_of_group = LAYOUT == kLayoutRunDual ? (order_entry & ~kTileAltBit) : order_entry;
+	const bool alt_tile = LAYOUT == kLayoutRunDual && (order_entry & kTileAltBit) != 0u;
 	if (threadIdx.x == 0) {
 		const uint64_t slot = tile_cost ? (uint64_t) (uintptr_t) (tile_cost + tile_of_group) : 0ull;
 		group_sched[0] = (uint32_t) (__builtin_readcyclecounter() >> 6); group_sched[1] = (uint32_t) slot; group_sched[2] = (uint32_t) (slot >> 32);
+		group_sched[3] = alt_tile ? 1u : 0u;
 	}
 	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
@@ -495,13 +504,17 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// entry j of a table belongs to cell clamp(j - kLutPad, 0, dim - 1): the pad entries repeat the edge cells
 		auto cell_of = [](uint32_t j, uint32_t n) { const int c = (int) j - kLutPad; return (uint32_t) (c < 0 ? 0 : (c > (int) n - 1 ? (int) n - 1 : c)); };
 		if (kUseLut && is_run_layout(LAYOUT)) {
-			// r = the run axis (z, or y for kLayoutRunY), o = the other column axis (y, or z); bricks: x fastest, then o, then r
-			const uint32_t nx = a.dim_x, nr = LAYOUT == kLayoutRunY ? a.dim_y : a.dim_z, no = LAYOUT == kLayoutRunY ? a.dim_z : a.dim_y;
-			const uint32_t nbo = LAYOUT == kLayoutRunY ? a.nbz : a.nby;
+			// r = the run axis (z, or y for kLayoutRunY), o = the other column axis (y, or z); bricks: x fastest, then o, then r.
+			// kLayoutRunDual: a tile that reads the copy along y builds ITS tables exactly like kLayoutRunY and marches with the
+			// y and z components of its texel-space ray exchanged — the table regions then meet the coordinates they were built for.
+			const bool along_y = LAYOUT == kLayoutRunY || alt_tile;
+			const uint32_t nx = a.dim_x, nr = along_y ? a.dim_y : a.dim_z, no = along_y ? a.dim_z : a.dim_y;
+			const uint32_t nbo = along_y ? a.nbz : a.nby;
 			const uint64_t slab = (uint64_t) a.nbx * nbo * kRunBrickBytes;
+			const uint64_t copy_base = alt_tile ? a.alt_copy : (uint64_t) (uintptr_t) vol;
 			for (uint32_t j = t; j < nr + 2 * kLutPad; j += kThreads) {
 				const uint32_t i = cell_of(j, nr);
-				const uint64_t z0 = (uint64_t) (uintptr_t) vol + (i >> 3) * slab + (i & 7u) * 4u;
+				const uint64_t z0 = copy_base + (i >> 3) * slab + (i & 7u) * 4u;
 				lut[2 * j] = (uint32_t) z0; lut[2 * j + 1] = (uint32_t) (z0 >> 32);
 			}
 			for (uint32_t j = t; j < nx + 2 * kLutPad; j += kThreads) { const uint32_t i = cell_of(j, nx); lut[L::x_at + j] = (i >> 3) * kRunBrickBytes + run_cell_spread(0, i & 7u); }
@@ -789,6 +802,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		// had a segment march the constant position 0.  The host switches the coordinate clamp back on (clamp_fetch) for
 		// views so far from the volume that fp32 rounding of the coordinates could leave (-1, N).
 		if (!alive) { kx = 0.0f; ky = 0.0f; A = mk3(0.0f, 0.0f, 0.0f); B = A; }
+		// kLayoutRunDual, tile on the copy along y: the texel-space ray is kept with y and z EXCHANGED — that is what the tile's
+		// address tables index (staging above); the few samples that are filtered put the two coordinates back (same fma, same bits)
+		if (LAYOUT == kLayoutRunDual && group_sched[3] != 0u) { float t = A.y; A.y = A.z; A.z = t; t = B.y; B.y = B.z; B.z = t; }
 		constexpr bool kTables = LAYOUT != kLayoutLinear && ADDR != kAddrWide;        // padded address tables (kLutPad)
 		auto march = [&](auto clamp_tag) {                    // instantiated for both settings: no per-sample test of the flag
 			constexpr bool kClamp = decltype(clamp_tag)::value;
@@ -863,8 +879,19 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 					const uint64_t inside = __builtin_amdgcn_fcmpf(kx, ky, kFcmpOLE);
 					if ((live & ~inside) != 0ull) { live &= inside; step_v = select_lanes(live, step); }
 				}
-				const float xb = VR_FMA(kx, A.x, B.x), yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);       // where the words were fetched
-				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(now, a, xb, yb, zb);                          // GPURenderer4.cu:76
+				const float xb = VR_FMA(kx, A.x, B.x);                                                            // where the words were fetched
+				float yb = VR_FMA(kx, A.y, B.y), zb = VR_FMA(kx, A.z, B.z);
+				// kLayoutRunDual: read again from LDS here, so that the flag occupies no register across the march — through an index the
+				// compiler cannot see through, or it hoists the read out of the loop (a volatile access would become a FLAT load with a
+				// vmcnt(0) wait behind it: the whole prefetch pipeline drained per filtered sample)
+				bool along_y = false;
+				if (LAYOUT == kLayoutRunDual) {
+					uint32_t opaque_zero;
+					asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+					along_y = group_sched[3u + opaque_zero] != 0u;
+				}
+				if (LAYOUT == kLayoutRunDual && along_y) { const float t = yb; yb = zb; zb = t; }                 // the true coordinates again
+				const float raw = tri_resolve<BPV, LAYOUT, kQ8>(now, a, xb, yb, zb, along_y);                 // GPURenderer4.cu:76
 				// GPURenderer4.cu:77 filtered TF: texel coordinate tb, entries floor(tb) and floor(tb)+1
 				const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
 				if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
@@ -882,8 +909,12 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 						const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
 						const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
 						const float lx = VR_FMA(d.x * inv, a.lh_x, xb), ly = VR_FMA(d.y * inv, a.lh_y, yb), lz = VR_FMA(d.z * inv, a.lh_z, zb);
-						TriFetch<BPV, LAYOUT> lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, lx, ly, lz, true);
-						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a, lx, ly, lz);
+						TriFetch<BPV, LAYOUT> lf;
+						if (LAYOUT == kLayoutRunDual) {                     // clamp with the true bounds, then hand the tile's table order over
+							const float cy = __builtin_amdgcn_fmed3f(ly, 0.0f, a.max_y), cz = __builtin_amdgcn_fmed3f(lz, 0.0f, a.max_z);
+							lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, __builtin_amdgcn_fmed3f(lx, 0.0f, a.max_x), along_y ? cz : cy, along_y ? cy : cz, false);
+						} else lf = tri_issue<BPV, ADDR, LAYOUT>(vol, a, lut, lx, ly, lz, true);
+						const float raw_l = tri_resolve<BPV, LAYOUT, kQ8>(lf, a, lx, ly, lz, along_y);
 						const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);       // 0 for lanes that are not shaded
 						c.x += diffuse; c.y += diffuse; c.z += diffuse;
 					}
@@ -949,6 +980,8 @@ static auto select_sampling(const RayKernelArgs &a, bool have_bricked, F &&visit
 			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutRun>(), false);
 		if (have_bricked && a.layout == kLayoutRunY)
 			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutRunY>(), false);
+		if (have_bricked && a.layout == kLayoutRunDual)
+			return visit(S(), V(), std::integral_constant<int, kAddr32>(), std::integral_constant<int, kLayoutRunDual>(), false);
 	}
 	if constexpr (nearest) {
 		if (have_bricked && a.layout == kLayoutVoxel) {
@@ -1024,7 +1057,7 @@ hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const 
 #define VR_RUN_LDS_PAD 16384
 #endif
 #ifndef VR_PAD_LAYOUTS
-#define VR_PAD_LAYOUTS ((1u << kLayoutRun) | (1u << kLayoutRunY))
+#define VR_PAD_LAYOUTS ((1u << kLayoutRun) | (1u << kLayoutRunY) | (1u << kLayoutRunDual))
 #endif
 		const uint32_t dynamic_lds = ((VR_PAD_LAYOUTS >> LAYOUT) & 1u) && !a.p.esl ? VR_RUN_LDS_PAD : 0;
 		hipLaunchKernelGGL((raymarch_kernel<SAMPLING, BPV, ADDR, LAYOUT>), dim3(a.tiles_x * a.tiles_y), dim3(threads), dynamic_lds, stream,
@@ -1080,6 +1113,31 @@ void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order
 
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t ntiles, hipStream_t stream) {
 	hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, ntiles);
+	return hipGetLastError();
+}
+
+// ---- choice between the two run copies per block of tiles (kLayoutRunDual) ------------------------------------------------------
+// choice[t] = t, with kTileAltBit set where the frame recorded on the copy along y was cheaper than the frame recorded on the copy
+// along z.  Decided per group of 64 consecutive tile numbers — one 8x8-tile block of the numbering, 256x128 pixels — from the SUMS of
+// the tile costs, and for the copy along y only if it wins by 5 % (VR_DUAL_KEEP_PERCENT, tuning aid): single tile costs are noisy (they depend on what else ran on the
+// CU), and tiles that read different copies share no cache lines — neighbours must agree (measured: alternating tiles +20 % frame
+// time, a per-tile choice +12 % on the perspective oblique pose, where the two copies are nearly level).  Both costs NULL:
+// alternating tiles (testing aid: the two copies meet at tile boundaries all over the frame).  Placement only.
+__global__ __launch_bounds__(64)
+void tile_choice_kernel(const uint32_t *__restrict__ cost_z, const uint32_t *__restrict__ cost_y, uint32_t *__restrict__ choice, uint32_t ntiles, uint32_t keep_percent) {
+	const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+	bool alt;
+	if (cost_z != nullptr && cost_y != nullptr) {
+		uint64_t z = t < ntiles ? cost_z[t] : 0u, y = t < ntiles ? cost_y[t] : 0u;
+		for (int d = 32; d >= 1; d >>= 1) { z += __shfl_xor(z, d, 64); y += __shfl_xor(y, d, 64); }
+		alt = y * 100u < z * keep_percent;
+	} else alt = ((t ^ (t >> 3)) & 1u) != 0u;
+	if (t < ntiles) choice[t] = t | (alt ? kTileAltBit : 0u);
+}
+
+hipError_t launch_tile_choice(const uint32_t *cost_z, const uint32_t *cost_y, uint32_t *choice, uint32_t ntiles, hipStream_t stream) {
+	static const uint32_t keep_percent = [] { const char *e = getenv("VR_DUAL_KEEP_PERCENT"); return e ? (uint32_t) atoi(e) : 95u; }();
+	hipLaunchKernelGGL(tile_choice_kernel, dim3((ntiles + 63u) / 64u), dim3(64), 0, stream, cost_z, cost_y, choice, ntiles, keep_percent);
 	return hipGetLastError();
 }
 
