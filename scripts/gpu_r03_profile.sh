@@ -18,7 +18,7 @@ python scripts/perf_probe.py --mode default > $OUT/per_view_default_trilinear.js
 python scripts/perf_probe.py --mode default --sampling nearest > $OUT/per_view_default_nearest.json && cat $OUT/per_view_default_nearest.json
 python scripts/perf_probe.py --mode default --sched 0 > $OUT/per_view_default_trilinear_sched0.json && cat $OUT/per_view_default_trilinear_sched0.json
 bash scripts/gpu_pmc.sh $OUT/pmc sq1,sq2,tcp1,tcc,fetch --views 0,1,2,3,4,5,6,7 || exit 1
-python scripts/pmc_per_view.py $OUT/pmc 4 > $OUT/pmc_per_view.txt; cat $OUT/pmc_per_view.txt
+python scripts/pmc_per_view.py $OUT/pmc 6 raymarch 2 > $OUT/pmc_per_view.txt; cat $OUT/pmc_per_view.txt
 bash scripts/gpu_pmc.sh $OUT/pmc_default sq1,sq2,tcc,fetch --mode default --views 0,1,2,3,4,5,6,7 || exit 1
-python scripts/pmc_per_view.py $OUT/pmc_default 4 > $OUT/pmc_default_per_view.txt; cat $OUT/pmc_default_per_view.txt
+python scripts/pmc_per_view.py $OUT/pmc_default 6 raymarch 2 > $OUT/pmc_default_per_view.txt; cat $OUT/pmc_default_per_view.txt
 find gpurun_out/profile_r03/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_full.csv

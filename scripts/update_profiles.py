@@ -18,6 +18,8 @@ commit = sys.argv[3] if len(sys.argv) > 3 else subprocess.check_output(["git", "
 shutil.copy(os.path.join(src, "kernel_stats_head.csv"), os.path.join(dst, f"{rnd}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(dst, f"{rnd}_bench_pmc_summary.txt"))
 shutil.copy(os.path.join(src, "stats_bench.json"), os.path.join(dst, f"{rnd}_bench_under_rocprof.json"))
+if os.path.exists(os.path.join(src, "timed_launches.json")):
+    shutil.copy(os.path.join(src, "timed_launches.json"), os.path.join(dst, f"{rnd}_bench_timed_launches.json"))
 vals = {}
 for line in open(os.path.join(src, "pmc_summary.txt")):
     m = re.match(r"\S+\s+(\S+)\s+n=\d+ last=\S+ mean=(\S+)", line)
@@ -28,7 +30,7 @@ with open(os.path.join(src, "stats_bench.json")) as f:
 traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
 json.dump({"nooptims_trilinear_1024_2048_n1": {"bytes_per_launch": round(traffic), "commit": commit,
                                                "kernel_ms": bench["roofline"]["kernel_ms"]},
-           "_source": f"profiles/{rnd}_bench_pmc_summary.txt: mean over the timed raymarch launches of rocprofv3 --pmc FETCH_SIZE "
+           "_source": f"profiles/{rnd}_bench_pmc_summary.txt: mean over the 16 TIMED raymarch launches of rocprofv3 --pmc FETCH_SIZE "
                       f"({vals['FETCH_SIZE']:.6g} KB, x2: gfx950 tallies 128-B requests at 64 B, calibrated on minmax_kernel which reads "
                       f"exactly 1 GiB and reports 524312 KB) + WRITE_SIZE ({vals['WRITE_SIZE']:.6g} KB, exact), separate passes",
            "_command": "python bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-extras"},
