@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3: workgroup tile stretched along the wave shape's long side (32x16 -> 16x32 -> 8x64 / 64x8 -> 128x4) on the run-brick views
+# round 3: workgroup tile stretched along the wave shape's long side (32x16 -> 16x32 -> 8x64 / 64x8 -> 128x4) on the run-brick views;
+# needs scripts/ubench/tile_stretch_experiment.patch applied (the product rejects lane maps >= 16)
 set -e
 mkdir -p gpurun_out/r03zi
 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "tile_mapping or layouts_agree" > gpurun_out/r03zi/pytest.log 2>&1 || { tail -30 gpurun_out/r03zi/pytest.log; exit 1; }
