@@ -62,9 +62,11 @@ int main() {
 		{ "oblique (-45,-45), 0.5 cell/px, 4x1 quads", 1, 0.5f, 0, 0.3f },
 		{ "oblique (-45,-45), 0.5 cell/px, 2x2 quads", 1, 0.5f, 2, 0.3f },
 	};
-	printf("%-64s %9s %9s %9s %9s %9s %9s %9s %9s\n", "pattern (ns per wave-instruction per CU)", "quad c", "quad c+1", "run8 x2", "run9 x2", "run8 al8", "u16 quad", "u16 run9", "u16 oct");
+	// "pair c / c+1" (round 3, candidate with 2.5 instead of 4.5 bytes per voxel): elements are PAIRS of voxels along a (2 bytes), the 9 pairs of
+	// a column (a,c) along b are contiguous (18 bytes + 2 of padding), a sample = two 4-byte loads at 2-BYTE alignment (slices c and c+1)
+	printf("%-64s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s\n", "pattern (ns per wave-instruction per CU)", "quad c", "quad c+1", "run8 x2", "run9 x2", "run8 al8", "u16 quad", "u16 run9", "u16 oct", "pair c", "pair c+1");
 	for (const Pat &p : pats) for (int cstep = 0; cstep < 2; cstep++) {
-		uint32_t hr9[64], hr8a[64], hq16[64], hr16[64], hoct[64];   // "u16 oct": ONE aligned 16-byte element per cell (2x2x2 two-byte voxels), quad brick order          // 2-byte voxels: 8-byte quad elements (two loads per sample), 72-byte runs (one 16-byte load)
+		uint32_t hr9[64], hr8a[64], hq16[64], hr16[64], hoct[64], hp0[64], hp1[64];   // "u16 oct": ONE aligned 16-byte element per cell (2x2x2 two-byte voxels), quad brick order          // 2-byte voxels: 8-byte quad elements (two loads per sample), 72-byte runs (one 16-byte load)
 		for (int l = 0; l < 64; l++) {
 			const int qd = l >> 4;
 			int gu = l & 3, gv = (l >> 2) & 3;
@@ -88,11 +90,14 @@ int main() {
 			hq16[l] = (brick * 512 + (spread(ia & 7, 0) | spread(ib & 7, 1) | spread(ic & 7, 2))) * 8;
 			hr16[l] = brick * 4608 + mort2(ia & 7, ib & 7) * 72 + (ic & 7) * 8;
 			hoct[l] = (brick * 512 + (spread(ia & 7, 0) | spread(ib & 7, 1) | spread(ic & 7, 2))) * 16;
+			hp0[l] = brick * 1280 + ((ia & 7) + (ic & 7) * 8) * 20 + (ib & 7) * 2;
+			hp1[l] = brick1 * 1280 + ((ia & 7) + (ic1 & 7) * 8) * 20 + (ib & 7) * 2;
 		}
 		char name[160];
 		snprintf(name, sizeof name, "%s, c&7=%d", p.name, cstep ? 3 : 6);
-		printf("%-64s %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f\n", name, run<4>(buf, out, d_off, hq0), run<4>(buf, out, d_off, hq1),
-		       run<8>(buf, out, d_off, hr), run<8>(buf, out, d_off, hr9), run<8>(buf, out, d_off, hr8a), run<8>(buf, out, d_off, hq16), run<16>(buf, out, d_off, hr16), run<16>(buf, out, d_off, hoct));
+		printf("%-64s %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f %9.2f\n", name, run<4>(buf, out, d_off, hq0), run<4>(buf, out, d_off, hq1),
+		       run<8>(buf, out, d_off, hr), run<8>(buf, out, d_off, hr9), run<8>(buf, out, d_off, hr8a), run<8>(buf, out, d_off, hq16), run<16>(buf, out, d_off, hr16), run<16>(buf, out, d_off, hoct),
+		       run<4>(buf, out, d_off, hp0), run<4>(buf, out, d_off, hp1));
 	}
 	return 0;
 }
