@@ -109,6 +109,22 @@ def test_trilinear_whole_frames_equal_the_restatement_c4(vr, gpu, c4):
     # and reads run bricks), both run copies; nothing was refused
     info = gpu.volume_info()
     assert (info.copies & (vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y)) == 27 and info.copies_refused == 0
+    # The oblique orthogonal view in the full march reads BOTH run copies, chosen per block of tiles by measurement: frames 0-3 of its
+    # parameter set run on the copy along z / y / z / y (the last two record tile costs), frames 4 and 5 read the per-block choice (the
+    # 32 cases above cycle the 16 remembered parameter sets: a set either starts at frame 0 again or continues at frame 1).  Every one of them is the
+    # restatement's frame (4.5 GiB copies: 64-bit table addresses).
+    for sampling, samp in (("trilinear", vr.SAMPLE_TRILINEAR), ("trilinear_q8", vr.SAMPLE_TRILINEAR_Q8)):
+        case = [c for c in _restatement_hash_cases("c4") if c["view"] == 1 and c["mode"] == "nooptims" and c["sampling"] == sampling][0]
+        scene.set_modes(esl=False, ray_threshold=1.0)
+        p = scene.frame_params(vr.benchmark_view(W, W, 1), samp)
+        layouts = []
+        for frame in range(6):
+            out = gpu.render_volume(p)
+            layouts.append(gpu.last_launch()["layout"])
+            assert fnv1a32(out) == case["fnv"] and int((out[..., 3] != 0).sum()) == case["nonzero_alpha"], (sampling, frame, layouts)
+        full = [2, 3, 2, 3, 6, 6, 6]                          # starts at frame 0, or at frame 1 when the loop above left this set remembered
+        assert layouts in (full[:6], full[1:7]), layouts
+    scene.set_modes(esl=True, ray_threshold=0.95)
 
 
 def test_partition_concat_equals_whole_frame(vr, gpu, c4):
