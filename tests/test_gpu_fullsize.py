@@ -140,6 +140,18 @@ def test_partition_concat_equals_whole_frame(vr, gpu, c4):
             split = dmod.FrameSplit(W, W, world, rank)
             parts.append(torch.from_numpy(gpu.render_volume(split.apply(scene.frame_params(view, vr.SAMPLE_TRILINEAR)))))
         assert np.array_equal(split.assemble(torch.stack(parts)).numpy(), whole), world
+    # the oblique orthogonal view: every rank measures and chooses its run copies per block of ITS tiles (frames 4 and 5 of a band set)
+    view = vr.benchmark_view(W, W, 1)
+    whole = gpu.render_volume(scene.frame_params(view, vr.SAMPLE_TRILINEAR))
+    parts = []
+    for rank in range(2):
+        split = dmod.FrameSplit(W, W, 2, rank)
+        p = split.apply(scene.frame_params(view, vr.SAMPLE_TRILINEAR))
+        frames = [gpu.render_volume(p) for _ in range(6)]
+        assert gpu.last_launch()["layout"] == 6
+        assert all(np.array_equal(f, frames[0]) for f in frames[1:]), rank
+        parts.append(torch.from_numpy(frames[-1]))
+    assert np.array_equal(split.assemble(torch.stack(parts)).numpy(), whole)
     scene.set_modes(esl=True, ray_threshold=0.95)
 
 
