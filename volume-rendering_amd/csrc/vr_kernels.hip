@@ -1402,11 +1402,14 @@ hipError_t launch_minmax(const void *volume, uint32_t bpv, uint32_t dim_x, uint3
 // Each wave keeps kHistCopies interleaved copies of the 256 bins in LDS (bin b of copy c at b * kHistCopies + c, c = lane % 8):
 // real volumes are dominated by a few values (air), and lanes that hit the same bin in one ds_add serialise — spreading them
 // over 8 copies in 8 different banks cuts that 8-fold.  16-byte loads, 4 in flight per thread.
-constexpr uint32_t kHistCopies = 8;
+// LDS histograms per wave: lanes that count the same bin in the same instruction serialise, so every wave keeps several copies (lane & (copies - 1)).
+// Measured on 1024^3 (scripts/feeder_probe.py): 1-byte voxels 3.3 / 4.0 / 4.6 / 3.1 TB/s with 4 / 8 / 16 / 32 copies, 2-byte voxels 4.7 / 4.8 / 4.4 / 4.0.
+template <int BPV> struct HistCopies { static constexpr uint32_t value = BPV == 1 ? 16u : 8u; };
 
 template <int BPV>
 __global__ __launch_bounds__(256)
 void histogram_kernel(const void *__restrict__ vol, uint64_t voxels, unsigned long long *__restrict__ hist) {
+	constexpr uint32_t kHistCopies = HistCopies<BPV>::value;
 	__shared__ uint32_t sh[4][256 * kHistCopies];
 	for (uint32_t i = threadIdx.x; i < 4 * 256 * kHistCopies; i += 256) ((uint32_t *) sh)[i] = 0;
 	__syncthreads();
