@@ -70,7 +70,7 @@ def random_params(rng, vr, bd, bs, ray_step, sampling):
 def test_random_scenes_match_oracle(vr, gpu, oracle):
     rng = np.random.default_rng(int(os.environ.get("VR_TEST_SEED", "20261004")))     # other seeds: VR_TEST_SEED=... pytest -m gpu -k random
     gpu.set_window_buffer(70, 50)
-    checked = nonempty = 0
+    checked = nonempty = dual_frames = 0
     try:
         for scene_i in range(14):
             vox, tf, esl, bd, bs, ray_step = random_scene(rng, oracle, vr)
@@ -88,8 +88,37 @@ def test_random_scenes_match_oracle(vr, gpu, oracle):
                                         f"esl {p.esl}: {ndiff} px differ, max delta {maxd}")
                     checked += 1
                     nonempty += int((out[..., 3] != 0).any())
+            # the full march of an ORTHOGONAL view that is not along an axis: six frames with the same parameters take the launch through
+            # the run copy along z, along y, the two recording frames and the per-block choice between the two copies (1-byte voxels,
+            # bricked layout, table addressing; otherwise the frames simply repeat)
+            p = random_params(rng, vr, bd, bs, ray_step, vr.SAMPLE_TRILINEAR if scene_i % 2 else vr.SAMPLE_TRILINEAR_Q8)
+            for _ in range(20):
+                if not p.view.perspective and min(abs(p.view.direction[j]) for j in range(3)) > 0.05:
+                    break
+                p = random_params(rng, vr, bd, bs, ray_step, p.sampling)
+            p.esl, p.ray_threshold = 0, 1.0
+            p.ray_step = float(np.float32(ray_step))                                   # (a four-fold step would select the clamping variant)
+            p.view.width, p.view.height = 64, 48                                     # 2 x 3 workgroup tiles at least
+            pitch = np.float32(2.0 / 48)
+            for j in range(3):
+                n_r = float(np.sqrt(sum(p.view.right_plane[i] ** 2 for i in range(3)))) or 1.0
+                n_u = float(np.sqrt(sum(p.view.up_plane[i] ** 2 for i in range(3)))) or 1.0
+                p.view.right_plane[j] = float(p.view.right_plane[j] / n_r * pitch)
+                p.view.up_plane[j] = float(p.view.up_plane[j] / n_u * pitch)
+            vr.whole_frame(p)
+            if vox.dtype == np.uint8:
+                gpu.set_layout(vr.LAYOUT_BRICKED)
+                gpu.set_wide_addressing(0)
+            ref = oracle.render(p, vox, tf, esl, threads=4)
+            layouts = []
+            for frame_i in range(6):
+                ndiff, maxd = compare_frames(gpu.render_volume(p), ref)
+                layouts.append(gpu.last_launch()["layout"])
+                assert ndiff == 0, f"scene {scene_i} dims {vox.shape} {vox.dtype} repeated frame {frame_i} layouts {layouts}: {ndiff} px differ, max delta {maxd}"
+            dual_frames += int(layouts[-1] == 6)
     finally:
         gpu.set_layout(vr.LAYOUT_BRICKED)
         gpu.set_wide_addressing(False)
     assert checked == 14 * 12
+    assert dual_frames >= 4, dual_frames               # the 1-byte scenes did reach the per-block copy choice
     assert nonempty >= checked // 2, nonempty          # the random views do look at the volume
