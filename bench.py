@@ -438,6 +438,8 @@ def run_rank(a):
                 "traffic": traffic.get("bytes_per_launch"), "traffic_commit": traffic.get("commit"),
                 "traffic_kernel_ms": traffic.get("kernel_ms"),
                 "traffic_GBs": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9, 1) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
+                # what the kernel actually moves against the HBM peak (the copies it reads are 4 - 4.5 bytes per voxel and fetched 1 - 2.4 times)
+                "traffic_frac_of_peak": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
                 "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
