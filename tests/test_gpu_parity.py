@@ -618,6 +618,18 @@ def test_error_conventions(vr, golden):
     assert b"band" in L.vr_hip_last_error(r._ctx)
     assert L.vr_hip_render(r._ctx, C.byref(p), buf.ctypes.data) == 0           # and the context still works
     assert np.array_equal(buf, golden.frame(case))
+    # policy switches and the profiling read-back: out-of-range values and premature calls are refused, the context keeps working
+    tx, ty = C.c_uint32(7), C.c_uint32(7)
+    assert L.vr_hip_read_tile_costs(r._ctx, None, 0, C.byref(tx), C.byref(ty)) == 5      # no frame with the cost map on yet
+    assert L.vr_hip_set_tile_scheduling(r._ctx, 3) == 1 and L.vr_hip_set_brick_plane(r._ctx, 8) == 1 and L.vr_hip_set_brick_plane(r._ctx, -2) == 1
+    assert L.vr_hip_set_tile_mapping(r._ctx, 16, 0, 0) == 1 and L.vr_hip_set_tile_mapping(r._ctx, 3, 0, 0) == 1 and L.vr_hip_set_tile_mapping(r._ctx, 0, 8, 0) == 1
+    assert L.vr_hip_last_launch(r._ctx, None) == 1
+    assert L.vr_hip_set_tile_scheduling(r._ctx, 2) == 0
+    assert L.vr_hip_render(r._ctx, C.byref(p), buf.ctypes.data) == 0 and np.array_equal(buf, golden.frame(case))
+    assert L.vr_hip_read_tile_costs(r._ctx, None, 0, C.byref(tx), C.byref(ty)) == 0 and tx.value * ty.value >= 1
+    small = np.zeros(max(1, tx.value * ty.value - 1), np.uint32)
+    assert L.vr_hip_read_tile_costs(r._ctx, small.ctypes.data, small.size if tx.value * ty.value > 1 else 0, C.byref(tx), C.byref(ty)) == 1   # buffer too small
+    assert L.vr_hip_set_tile_scheduling(r._ctx, 1) == 0
     ctx = C.c_void_p()
     assert L.vr_hip_create(99, C.byref(ctx)) == 2                              # VR_ERR_NO_DEVICE
     r.close()
