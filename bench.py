@@ -443,7 +443,8 @@ def run_rank(a):
                 "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
-                                         "(every other TRILINEAR view), 4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
+                                         "(every other TRILINEAR view), 6 both run copies chosen per block of tiles (orthogonal views that are not along an axis, from their fifth frame on), "
+                                         "4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
                 "kernel_ms_note": ("N >= 2: the three frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
                                    "launch that shares the chip with its neighbour — longer than the kernel alone; `value` (frames per second over all ranks) is the figure "
