@@ -280,6 +280,10 @@ uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
 #define VR_COPY_ALL      0x7fu
 #define VR_COPY_KINDS    7
 int vr_hip_prepare(vr_ctx *ctx, uint32_t copies);
+/* Testing aid: the raw bytes of one resident brick copy (kind = bit index of its VR_COPY_* flag), so that a test can hold every copy
+ * builder against a host-side construction of the layout, byte for byte.  *bytes_out (optional) = size of the copy; host_out may be
+ * NULL for a size query.  VR_ERR_NOT_READY if the copy is not resident, VR_ERR_INVALID if capacity is too small. */
+int vr_hip_download_copy(vr_ctx *ctx, uint32_t kind, void *host_out, uint64_t capacity, uint64_t *bytes_out);
 
 /* ---- what the resident volume occupies in HBM, and giving some of it back ----
  * The bricked layout keeps the reference's linear array (feeders, download, building copies) next to the brick copies built so

@@ -2,7 +2,7 @@
 """Whole-frame goldens at the BASELINE sizes, rendered by the REFERENCE'S OWN CPU path (oracle/_ref/libvolr_ref.so =
 CPURenderer.cpp:43-53 compiled from /root/reference by oracle/Makefile).  TEST INFRASTRUCTURE, build container only.
 
-  C3: shell 512^3  (seed 1) @ 1920x1080      C4: shell 1024^3 (seed 1) @ 2048x2048
+  C2: shell 256^3 (seed 1) @ 1024x1024    C3: shell 512^3  (seed 1) @ 1920x1080      C4: shell 1024^3 (seed 1) @ 2048x2048
   8 benchmark views (VolR.cpp:232-248) x {default: ESL on, threshold 0.95; nooptims: ESL off, threshold 1.0}, light 0.6
 
 Only hashes travel (tests/golden/golden_fullsize.json): FNV-1a32 of the RGBA8 frame + the number of pixels with
@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libvolr_ref.so")
 OUT = os.path.join(ROOT, "tests", "golden", "golden_fullsize.json")
 
-CONFIGS = {"c3": (512, 1920, 1080), "c4": (1024, 2048, 2048)}
+CONFIGS = {"c2": (256, 1024, 1024), "c3": (512, 1920, 1080), "c4": (1024, 2048, 2048)}
 MODES = {"default": (1, 0.95), "nooptims": (0, 1.0)}
 
 

@@ -80,13 +80,13 @@ def _restatement_hash_cases(config):
         return [c for c in json.load(f)["cases"] if c["config"] == config]
 
 
-def _check_trilinear_whole_frames(vr, gpu, scene, cases, width, height):
+def _check_trilinear_whole_frames(vr, gpu, scene, cases, width, height, expect=32):
     """TRILINEAR / TRILINEAR_Q8 whole frames under the AUTOMATIC per-view policy (brick copy, tile phase, lane order as
     vr_hip_api.cpp picks them) == the frames of the CPU restatement (oracle/gen_golden_fullsize_trilinear.py): FNV-1a32 and
     covered-pixel count.  Pins HIP == restatement, not HIP == GPURenderer4 (which cannot run here): parity of the trilinear
     sampler against the reference stays unpinned, DESIGN.md section 1."""
-    assert len(cases) == 32
-    samp = {"trilinear": vr.SAMPLE_TRILINEAR, "trilinear_q8": vr.SAMPLE_TRILINEAR_Q8}
+    assert len(cases) == expect, len(cases)
+    samp = {"trilinear": vr.SAMPLE_TRILINEAR, "trilinear_q8": vr.SAMPLE_TRILINEAR_Q8, "nearest": vr.SAMPLE_NEAREST}
     gpu.set_brick_plane(-1)
     gpu.set_tile_mapping(-1, 0, 0)
     bad = []
@@ -189,6 +189,28 @@ def _band_check(vr, gpu, oracle, scene, vox, width, height, view_i, first_band, 
     scene.set_modes(esl=True, ray_threshold=0.95)
 
 
+def test_config2_256_at_1024_whole_frames(vr, gpu):
+    """BASELINE config 2 (256^3 synthetic uint8 volume, 1024x1024, trilinear + alpha composite) in its STATED mode and from every
+    benchmark pose: 8 views x {default, no optims} x {NEAREST == the reference's own CPURenderer frames (oracle/_ref), TRILINEAR and
+    Q8 == the CPU restatement} = 48 whole-frame hashes, under the automatic per-view policy (copies, phases, lane orders)."""
+    gpu.set_layout(vr.LAYOUT_BRICKED)
+    gpu.generate_volume("shell", 256, seed=1)
+    assert fnv1a32(gpu.download_volume()) == "6d5baf38"
+    mm, _, _, _ = gpu.volume_minmax()
+    scene = vr.Scene().set_volume(dims=(256, 256, 256), minmax=mm)
+    gpu.set_transfer_fn(scene.tf, scene.esl)
+    gpu.set_window_buffer(1024, 1024)
+    cases = _reference_hash_cases("c2")
+    assert len(cases) == 16
+    for case in cases:
+        scene.set_modes(esl=(case["mode"] == "default"), ray_threshold=(0.95 if case["mode"] == "default" else 1.0))
+        assert np.float32(scene.params.ray_step) == np.float32(case["ray_step"])
+        out = gpu.render_volume(scene.frame_params(vr.benchmark_view(1024, 1024, case["view"]), vr.SAMPLE_NEAREST))
+        assert fnv1a32(out) == case["fnv"], (case["view"], case["mode"])
+        assert int((out[..., 3] != 0).sum()) == case["nonzero_alpha"]
+    _check_trilinear_whole_frames(vr, gpu, scene, _restatement_hash_cases("c2"), 1024, 1024)
+
+
 def test_config3_512_at_1080p(vr, gpu, oracle):
     """BASELINE config 3: 512^3 volume, 1920x1080, early ray termination via the wavefront ballot, ESL on/off."""
     gpu.generate_volume("shell", 512, seed=1)
@@ -252,6 +274,12 @@ def test_config5_2048_u16_at_4096(vr, gpu, oracle):
     assert np.array_equal(vox[z], expect)
     _band_check(vr, gpu, oracle, scene, vox, w, w, 1, 140, modes=("default",))
     _band_check(vr, gpu, oracle, scene, vox, w, w, 6, 77, modes=("nooptims",))
+    # Whole 4096^2 frames against the CPU restatement (oracle/gen_golden_fullsize_trilinear.py, hashes only travel): the default mode
+    # for all 8 views in TRILINEAR and NEAREST, the full march for views 0 (along an axis: oct bricks behind 64-bit tables, 128 GiB),
+    # 1 (oblique orthogonal, oct bricks) and 5 (oblique perspective, quad bricks) — 19 frames under the automatic policy.
+    del vox
+    _check_trilinear_whole_frames(vr, gpu, scene, _restatement_hash_cases("c5"), w, w, expect=19)
+    vox = None
     # one whole frame for the record (not asserted on time): full march, TRILINEAR
     scene.set_modes(esl=False, ray_threshold=1.0)
     import torch

@@ -116,6 +116,7 @@ def lib():
         "vr_hip_volume_info": (C.c_int, [vp, P(VrVolumeInfo)]),
         "vr_hip_release_linear_copy": (C.c_int, [vp]),
         "vr_hip_prepare": (C.c_int, [vp, u32]),
+        "vr_hip_download_copy": (C.c_int, [vp, u32, vp, u64, vp]),
         "vr_hip_multi_create": (C.c_int, [C.c_int, P(C.c_int), P(vp)]),
         "vr_hip_multi_destroy": (None, [vp]),
         "vr_hip_multi_last_error": (C.c_char_p, [vp]),

@@ -1020,6 +1020,21 @@ int vr_hip_prepare(vr_ctx *c, uint32_t copies) {
 	return worst;
 }
 
+int vr_hip_download_copy(vr_ctx *c, uint32_t kind, void *host_out, uint64_t capacity, uint64_t *bytes_out) {
+	if (c == nullptr) return VR_ERR_INVALID;
+	if (kind >= kCopyKinds) return fail(c, VR_ERR_INVALID, "unknown copy kind");
+	if (c->copy[kind] == nullptr) return fail(c, VR_ERR_NOT_READY, "this brick copy is not resident (render a frame that reads it, or vr_hip_prepare)");
+	uint64_t bytes = copy_bytes(c, kind);
+	if (kind == kCopyRunZ || kind == kCopyRunY) bytes -= 16;     // the allocation's tail slack is not part of the copy
+	if (bytes_out) *bytes_out = bytes;
+	if (host_out == nullptr) return VR_OK;
+	if (capacity < bytes) return fail(c, VR_ERR_INVALID, "buffer too small for this copy");
+	VR_TRY(c, hipSetDevice(c->device));
+	VR_TRY(c, drain(c));
+	VR_TRY(c, hipMemcpy(host_out, c->copy[kind], bytes, hipMemcpyDeviceToHost));
+	return VR_OK;
+}
+
 int vr_hip_release_linear_copy(vr_ctx *c) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (c->dim[0] == 0) return fail(c, VR_ERR_NOT_READY, "release_linear_copy before set_volume");

@@ -1141,145 +1141,144 @@ hipError_t launch_tile_choice(const uint32_t *cost_z, const uint32_t *cost_y, ui
 	return hipGetLastError();
 }
 
-// ---- linear -> bricked copy ------------------------------------------------------------------------------------------
+// ---- linear -> brick copies: LDS-tiled streaming transposes ---------------------------------------------------------------------
+//
+// Every copy (quad bricks per chunk plane, voxel bricks, oct bricks, run bricks along z / y) is built by ONE kernel shape: a workgroup
+// owns a STRIP of kStripBricks bricks along x — contiguous in the copy, because bricks are stored x fastest — stages the voxel rows the
+// strip's elements are made of (8 x-bricks + 1 voxel wide, 8 or 9 rows x 8 or 9 slices: the +1 neighbours, indices clamped at the upper
+// faces, where the interpolation weight is exactly 0) with aligned 16-byte loads into LDS, builds the elements from LDS and writes the
+// strip with full 16-byte stores in copy order (256 threads x 16 bytes = 4 KiB contiguous per pass).  HBM sees the linear array about
+// once (the y+1 / z+1 rows of the neighbouring strips mostly hit the L2) and the copy exactly once: bound = HBM, bytes = linear + copy.
+// (Before: one thread per 4-byte element, four scattered byte loads and four byte stores each — 0.06-0.16 of the HBM peak.)
+enum : int { kBuildQuad = 0, kBuildVoxel = 1, kBuildOct = 2, kBuildRunZ = 3, kBuildRunY = 4 };
+constexpr uint32_t kStripBricks = 16, kStripThreads = 256;
 
-template <int BPV>
-__global__ __launch_bounds__(256)
-void brickify_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t plane, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
-                     uint32_t nbx, uint32_t nby, uint32_t nbz) {
+template <int BPV, int KIND> struct StripCfg {
+	static constexpr uint32_t ny = KIND == kBuildVoxel ? 8u : 9u;                                            // staged rows along y
+	static constexpr uint32_t nz = (KIND == kBuildQuad || KIND == kBuildVoxel) ? 8u : 9u;                    // staged slices along z
+	static constexpr uint32_t row_voxels = kStripBricks * 8u + 1u;                                           // + the x+1 neighbour of the last cell
+	static constexpr uint32_t pitch_words = (row_voxels * BPV + 3u) / 4u + (((row_voxels * BPV + 3u) / 4u) % 2u == 0u ? 1u : 0u);   // odd: rows spread over the banks
+	static constexpr uint32_t brick_bytes = KIND == kBuildQuad ? 512u * 4u * BPV : KIND == kBuildVoxel ? 512u * BPV : KIND == kBuildOct ? 512u * 8u * BPV : kRunBrickBytes;
+	static constexpr uint32_t chunks_per_brick = brick_bytes / 16u;
+};
+
+template <int BPV, int KIND, int PLANE>
+__global__ __launch_bounds__(kStripThreads)
+void brick_strip_kernel(const void *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, uint32_t nbx) {
+	typedef StripCfg<BPV, KIND> S;
 	typedef typename VoxelT<BPV>::type V;
-	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
-	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
-		const uint64_t brick = o / kBrickPitch;
-		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
-		// undo the Morton order
-		const uint32_t lz = brick_collect(BPV, plane, 2, local), lx = brick_collect(BPV, plane, 0, local), ly = brick_collect(BPV, plane, 1, local);
-		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
-		const uint32_t by = br / nbx, bx = br - by * nbx;
-		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
-		V q[4] = { 0, 0, 0, 0 };
-		if (x < dim_x && y < dim_y && z < dim_z) {
-			// indices clamped at the upper faces: the clamped neighbours only ever get weight 0
-			const uint32_t zc = z;
-			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1;
-			const V *slice = (const V *) lin + (uint64_t) zc * dim_y * dim_x;
-			q[0] = slice[(uint64_t) y * dim_x + x];  q[1] = slice[(uint64_t) y * dim_x + x1];
-			q[2] = slice[(uint64_t) y1 * dim_x + x]; q[3] = slice[(uint64_t) y1 * dim_x + x1];
+	__shared__ uint32_t rows[S::ny * S::nz * S::pitch_words];
+	// brick order: x fastest, then the "other" axis, then the outer axis (quad / voxel / oct / runs along z: y then z; runs along y: z then y)
+	const uint32_t bx0 = blockIdx.x * kStripBricks, mid = blockIdx.y, outer = blockIdx.z;
+	const uint32_t y0 = (KIND == kBuildRunY ? outer : mid) * 8u, z0 = (KIND == kBuildRunY ? mid : outer) * 8u, x0 = bx0 * 8u;
+	const uint32_t t = threadIdx.x;
+	// -- stage: row (dy, dz) = voxels x0 .. x0 + 128 of line (min(y0 + dy, Y-1), min(z0 + dz, Z-1)), x clamped to X-1
+	{
+		const bool fast = ((uint64_t) dim_x * BPV) % 16u == 0u && (uint64_t) x0 + kStripBricks * 8u <= dim_x && ((uintptr_t) lin & 15u) == 0u;
+		constexpr uint32_t vec_per_row = (kStripBricks * 8u * BPV) / 16u;                 // whole 16-byte chunks of a row (the +1 voxel comes separately)
+		if (fast) {
+			for (uint32_t i = t; i < S::ny * S::nz * vec_per_row; i += kStripThreads) {
+				const uint32_t r = i / vec_per_row, cx = i - r * vec_per_row, dy = r % S::ny, dz = r / S::ny;
+				const uint32_t y = y0 + dy < dim_y ? y0 + dy : dim_y - 1u, z = z0 + dz < dim_z ? z0 + dz : dim_z - 1u;
+				const uint4 v = *(const uint4 *) ((const uint8_t *) lin + (((uint64_t) z * dim_y + y) * dim_x + x0) * BPV + (uint64_t) cx * 16u);
+				uint32_t *dst = rows + r * S::pitch_words + cx * 4u;
+				dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+			}
+			for (uint32_t r = t; r < S::ny * S::nz; r += kStripThreads) {                 // the x+1 neighbour of the strip's last cell (clamped at the face)
+				const uint32_t dy = r % S::ny, dz = r / S::ny;
+				const uint32_t y = y0 + dy < dim_y ? y0 + dy : dim_y - 1u, z = z0 + dz < dim_z ? z0 + dz : dim_z - 1u;
+				const uint32_t x = x0 + kStripBricks * 8u < dim_x ? x0 + kStripBricks * 8u : dim_x - 1u;
+				((V *) (rows + r * S::pitch_words))[kStripBricks * 8u] = ((const V *) lin)[((uint64_t) z * dim_y + y) * dim_x + x];
+			}
+		} else {
+			for (uint32_t i = t; i < S::ny * S::nz * S::row_voxels; i += kStripThreads) {
+				const uint32_t r = i / S::row_voxels, lx = i - r * S::row_voxels, dy = r % S::ny, dz = r / S::ny;
+				const uint32_t y = y0 + dy < dim_y ? y0 + dy : dim_y - 1u, z = z0 + dz < dim_z ? z0 + dz : dim_z - 1u;
+				const uint32_t x = x0 + lx < dim_x ? x0 + lx : dim_x - 1u;
+				((V *) (rows + r * S::pitch_words))[lx] = ((const V *) lin)[((uint64_t) z * dim_y + y) * dim_x + x];
+			}
 		}
-		V *dst = (V *) out + o * 4;
-		dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 	}
+	__syncthreads();
+	auto vox = [&](uint32_t lx, uint32_t dy, uint32_t dz) -> uint32_t { return ((const V *) (rows + (dz * S::ny + dy) * S::pitch_words))[lx]; };
+	// one 32-bit word of quad element (lx, ly, lz) of slice lz: 1-byte voxels: the whole element; 2-byte: half h (0: row y, 1: row y+1)
+	auto quad_word = [&](uint32_t lx, uint32_t ly, uint32_t lz, uint32_t h) -> uint32_t {
+		if (BPV == 1) return vox(lx, ly, lz) | (vox(lx + 1u, ly, lz) << 8) | (vox(lx, ly + 1u, lz) << 16) | (vox(lx + 1u, ly + 1u, lz) << 24);
+		return vox(lx, ly + h, lz) | (vox(lx + 1u, ly + h, lz) << 16);
+	};
+	const uint32_t bricks_here = nbx - bx0 < kStripBricks ? nbx - bx0 : kStripBricks;
+	const uint64_t first_brick = ((uint64_t) outer * gridDim.y + mid) * nbx + bx0;
+	uint4 *dst = out + first_brick * S::chunks_per_brick;
+	for (uint32_t c = t; c < bricks_here * S::chunks_per_brick; c += kStripThreads) {
+		const uint32_t b = c / S::chunks_per_brick, in = c - b * S::chunks_per_brick, xb = b * 8u;      // brick of the strip, chunk inside it
+		uint32_t w[4];
+		#pragma unroll
+		for (uint32_t i = 0; i < 4u; i++) {
+			uint32_t word = 0u;
+			if (KIND == kBuildQuad || KIND == kBuildOct) {
+				// element index inside the brick and which word of it: quad u8: 1 word per element; quad u16: 2; oct (u16): 4
+				constexpr uint32_t words_per_elem = KIND == kBuildOct ? 4u : (uint32_t) BPV;
+				const uint32_t local = (in * 4u + i) / words_per_elem, part = (in * 4u + i) % words_per_elem;
+				const uint32_t lx = brick_collect(BPV, PLANE, 0, local), ly = brick_collect(BPV, PLANE, 1, local), lz = brick_collect(BPV, PLANE, 2, local);
+				if (x0 + xb + lx < dim_x && y0 + ly < dim_y && z0 + lz < dim_z)
+					word = KIND == kBuildOct ? quad_word(xb + lx, ly, lz + (part >> 1), part & 1u) : quad_word(xb + lx, ly, lz, part);
+			} else if (KIND == kBuildVoxel) {
+				constexpr uint32_t per_word = 4u / BPV;
+				#pragma unroll
+				for (uint32_t j = 0; j < per_word; j++) {
+					const uint32_t local = (in * 4u + i) * per_word + j;
+					const uint32_t lx = brick_collect(BPV, kPlaneXY, 0, local), ly = brick_collect(BPV, kPlaneXY, 1, local), lz = brick_collect(BPV, kPlaneXY, 2, local);
+					if (x0 + xb + lx < dim_x && y0 + ly < dim_y && z0 + lz < dim_z) word |= vox(xb + lx, ly, lz) << (8u * BPV * j);
+				}
+			} else {
+				// run bricks: 64 cell columns (2-D Morton over x and the other axis) x 9 elements along the run axis; element 8 = the next brick's first
+				const uint32_t e = in * 4u + i, cell = e / kRunLen, k = e - cell * kRunLen;
+				const uint32_t lx = (cell & 1u) | ((cell >> 1) & 2u) | ((cell >> 2) & 4u), lo = ((cell >> 1) & 1u) | ((cell >> 2) & 2u) | ((cell >> 3) & 4u);
+				if (KIND == kBuildRunZ) {
+					if (x0 + xb + lx < dim_x && y0 + lo < dim_y) word = quad_word(xb + lx, lo, k, 0u);
+				} else if (x0 + xb + lx < dim_x && z0 + lo < dim_z) {           // element = the (x,z) neighbourhood of row y0 + k
+					word = vox(xb + lx, k, lo) | (vox(xb + lx + 1u, k, lo) << 8) | (vox(xb + lx, k, lo + 1u) << 16) | (vox(xb + lx + 1u, k, lo + 1u) << 24);
+				}
+			}
+			w[i] = word;
+		}
+		dst[c] = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+}
+
+template <int BPV, int KIND, int PLANE>
+static hipError_t launch_strip(const void *linear, void *copy, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+	const uint32_t nbx = (dim_x + 7u) / 8u, nby = (dim_y + 7u) / 8u, nbz = (dim_z + 7u) / 8u;
+	const dim3 grid((nbx + kStripBricks - 1u) / kStripBricks, KIND == kBuildRunY ? nbz : nby, KIND == kBuildRunY ? nby : nbz);
+	hipLaunchKernelGGL((brick_strip_kernel<BPV, KIND, PLANE>), grid, dim3(kStripThreads), 0, stream, linear, (uint4 *) copy, dim_x, dim_y, dim_z, nbx);
+	return hipGetLastError();
 }
 
 hipError_t launch_brickify(const void *linear, void *bricked, uint32_t bpv, uint32_t plane, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
                            hipStream_t stream) {
-	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge,
-	               nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
-	if (bpv == 1) hipLaunchKernelGGL(brickify_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	else          hipLaunchKernelGGL(brickify_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, bricked, plane, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	return hipGetLastError();
+	if (bpv == 2) return launch_strip<2, kBuildQuad, kPlaneXY>(linear, bricked, dim_x, dim_y, dim_z, stream);       // 2-byte voxels: one order (Z-order)
+	if (plane == kPlaneXZ) return launch_strip<1, kBuildQuad, kPlaneXZ>(linear, bricked, dim_x, dim_y, dim_z, stream);
+	if (plane == kPlaneYZ) return launch_strip<1, kBuildQuad, kPlaneYZ>(linear, bricked, dim_x, dim_y, dim_z, stream);
+	return launch_strip<1, kBuildQuad, kPlaneXY>(linear, bricked, dim_x, dim_y, dim_z, stream);
 }
 
-// linear -> oct bricks (2-byte voxels): element o of the 2-byte brick order holds the 2x2x2 neighbourhood of its cell, indices
-// clamped at the upper faces (the clamped neighbours only ever get weight 0); 16 bytes per element, written as one uint4
-__global__ __launch_bounds__(256)
-void brickify_oct_kernel(const uint16_t *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
-                         uint32_t nbx, uint32_t nby, uint32_t nbz) {
-	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
-	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
-		const uint64_t brick = o / kBrickPitch;
-		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
-		const uint32_t lz = brick_collect(2, kPlaneXY, 2, local), lx = brick_collect(2, kPlaneXY, 0, local), ly = brick_collect(2, kPlaneXY, 1, local);
-		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
-		const uint32_t by = br / nbx, bx = br - by * nbx;
-		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
-		uint4 e = { 0u, 0u, 0u, 0u };
-		if (x < dim_x && y < dim_y && z < dim_z) {
-			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, y1 = y + 1 < dim_y ? y + 1 : dim_y - 1, z1 = z + 1 < dim_z ? z + 1 : dim_z - 1;
-			const uint16_t *s0 = lin + (uint64_t) z * dim_y * dim_x, *s1 = lin + (uint64_t) z1 * dim_y * dim_x;
-			e.x = s0[(uint64_t) y * dim_x + x] | ((uint32_t) s0[(uint64_t) y * dim_x + x1] << 16);
-			e.y = s0[(uint64_t) y1 * dim_x + x] | ((uint32_t) s0[(uint64_t) y1 * dim_x + x1] << 16);
-			e.z = s1[(uint64_t) y * dim_x + x] | ((uint32_t) s1[(uint64_t) y * dim_x + x1] << 16);
-			e.w = s1[(uint64_t) y1 * dim_x + x] | ((uint32_t) s1[(uint64_t) y1 * dim_x + x1] << 16);
-		}
-		out[o] = e;
-	}
-}
-
+// linear -> oct bricks (2-byte voxels): element o of the 2-byte brick order holds the 2x2x2 neighbourhood of its cell, 16 bytes
 hipError_t launch_brickify_oct(const void *linear, void *oct_bricks, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
-	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge, nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
-	hipLaunchKernelGGL(brickify_oct_kernel, dim3(16384), dim3(256), 0, stream, (const uint16_t *) linear, (uint4 *) oct_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	return hipGetLastError();
+	return launch_strip<2, kBuildOct, kPlaneXY>(linear, oct_bricks, dim_x, dim_y, dim_z, stream);
 }
 
 // linear -> voxel bricks: element o of the (x,y)-plane brick order holds the voxel itself (zero outside the volume)
-template <int BPV>
-__global__ __launch_bounds__(256)
-void brickify_voxel_kernel(const void *__restrict__ lin, void *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
-                           uint32_t nbx, uint32_t nby, uint32_t nbz) {
-	typedef typename VoxelT<BPV>::type V;
-	const uint64_t total = (uint64_t) nbx * nby * nbz * kBrickPitch;
-	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
-		const uint64_t brick = o / kBrickPitch;
-		const uint32_t local = (uint32_t) (o - brick * kBrickPitch);
-		const uint32_t lz = brick_collect(BPV, kPlaneXY, 2, local), lx = brick_collect(BPV, kPlaneXY, 0, local), ly = brick_collect(BPV, kPlaneXY, 1, local);
-		const uint32_t bz = (uint32_t) (brick / ((uint64_t) nbx * nby)), br = (uint32_t) (brick - (uint64_t) bz * nbx * nby);
-		const uint32_t by = br / nbx, bx = br - by * nbx;
-		const uint32_t x = bx * kBrickEdge + lx, y = by * kBrickEdge + ly, z = bz * kBrickEdge + lz;
-		((V *) out)[o] = (x < dim_x && y < dim_y && z < dim_z) ? ((const V *) lin)[((uint64_t) z * dim_y + y) * dim_x + x] : (V) 0;
-	}
-}
-
 hipError_t launch_brickify_voxel(const void *linear, void *voxel_bricks, uint32_t bpv, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
-	const uint32_t nbx = (dim_x + kBrickEdge - 1) / kBrickEdge, nby = (dim_y + kBrickEdge - 1) / kBrickEdge, nbz = (dim_z + kBrickEdge - 1) / kBrickEdge;
-	if (bpv == 1) hipLaunchKernelGGL(brickify_voxel_kernel<1>, dim3(16384), dim3(256), 0, stream, linear, voxel_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	else          hipLaunchKernelGGL(brickify_voxel_kernel<2>, dim3(16384), dim3(256), 0, stream, linear, voxel_bricks, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	return hipGetLastError();
+	if (bpv == 1) return launch_strip<1, kBuildVoxel, kPlaneXY>(linear, voxel_bricks, dim_x, dim_y, dim_z, stream);
+	return launch_strip<2, kBuildVoxel, kPlaneXY>(linear, voxel_bricks, dim_x, dim_y, dim_z, stream);
 }
 
-// linear -> run bricks: one thread per stored element; element k = 8 of a run is the first element of the next brick along the run
-// axis (index clamped at the upper face, where the interpolation weight is exactly 0).  RUN_Y = false: runs along z, element =
-// (x,y) neighbourhood of slice z; RUN_Y = true: runs along y, element = (x,z) neighbourhood of row y.
-template <bool RUN_Y>
-__global__ __launch_bounds__(256)
-void brickify_run_kernel(const uint8_t *__restrict__ lin, uint8_t *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z,
-                         uint32_t nbx, uint32_t nbo, uint32_t nbr) {
-	const uint32_t dim_o = RUN_Y ? dim_z : dim_y, dim_r = RUN_Y ? dim_y : dim_z;       // other column axis / run axis
-	const uint64_t total = (uint64_t) nbx * nbo * nbr * 64u * kRunLen;
-	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	for (uint64_t o = (uint64_t) blockIdx.x * 256 + threadIdx.x; o < total; o += stride) {
-		const uint64_t brick = o / (64u * kRunLen);
-		const uint32_t in = (uint32_t) (o - brick * (64u * kRunLen)), cell = in / kRunLen, k = in - cell * kRunLen;
-		const uint32_t lx = (cell & 1u) | ((cell >> 1) & 2u) | ((cell >> 2) & 4u), lo = ((cell >> 1) & 1u) | ((cell >> 2) & 2u) | ((cell >> 3) & 4u);
-		const uint32_t br_ = (uint32_t) (brick / ((uint64_t) nbx * nbo)), rest = (uint32_t) (brick - (uint64_t) br_ * nbx * nbo);
-		const uint32_t bo = rest / nbx, bx = rest - bo * nbx;
-		const uint32_t x = bx * 8u + lx, oc = bo * 8u + lo;
-		uint32_t r = br_ * 8u + k;
-		uint8_t q[4] = { 0, 0, 0, 0 };
-		if (x < dim_x && oc < dim_o && br_ * 8u < dim_r) {
-			if (r > dim_r - 1) r = dim_r - 1;
-			const uint32_t x1 = x + 1 < dim_x ? x + 1 : dim_x - 1, o1 = oc + 1 < dim_o ? oc + 1 : dim_o - 1;
-			auto voxel = [&](uint32_t xx, uint32_t oo) {          // (x, other, run) -> (x, y, z)
-				const uint32_t yy = RUN_Y ? r : oo, zz = RUN_Y ? oo : r;
-				return lin[((uint64_t) zz * dim_y + yy) * dim_x + xx];
-			};
-			q[0] = voxel(x, oc); q[1] = voxel(x1, oc); q[2] = voxel(x, o1); q[3] = voxel(x1, o1);
-		}
-		uint8_t *dst = out + o * 4;
-		dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
-	}
-}
-
+// linear -> run bricks (1-byte voxels): element k = 8 of a run is the first element of the next brick along the run axis (index clamped at
+// the upper face, where the interpolation weight is exactly 0).  Runs along z: element = (x,y) neighbourhood of slice z; runs along y:
+// element = (x,z) neighbourhood of row y.
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
-	const uint32_t nbx = (dim_x + 7) / 8, nby = (dim_y + 7) / 8, nbz = (dim_z + 7) / 8;
-	if (run_layout == kLayoutRunY)
-		hipLaunchKernelGGL(brickify_run_kernel<true>, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nbz, nby);
-	else
-		hipLaunchKernelGGL(brickify_run_kernel<false>, dim3(16384), dim3(256), 0, stream, (const uint8_t *) linear, (uint8_t *) run_copy, dim_x, dim_y, dim_z, nbx, nby, nbz);
-	return hipGetLastError();
+	if (run_layout == kLayoutRunY) return launch_strip<1, kBuildRunY, kPlaneXY>(linear, run_copy, dim_x, dim_y, dim_z, stream);
+	return launch_strip<1, kBuildRunZ, kPlaneXY>(linear, run_copy, dim_x, dim_y, dim_z, stream);
 }
 
 // ---- feeders: per-ESL-block min/max (RaycasterBase.cpp:101-117) as an HBM-streaming reduction --------------------------
@@ -1463,29 +1462,61 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 	return h;
 }
 
+// One thread per 16-byte chunk of the array (16 or 8 consecutive voxels along x, wrapping into the next row / slice), one 16-byte store.
+// The shell's 1000 * d2 / (N * N) is an exact integer quotient (< 12000) formed from a double-precision estimate and corrected by its
+// remainder — the 64-bit integer division it replaces was what the old one-voxel-per-thread kernel spent its time in.
+template <int BPV>
+__device__ __forceinline__ uint32_t synthetic_voxel(uint32_t kind, uint64_t idx, long long ax, long long ayz2, long long nn, double inv_nn, uint32_t seed) {
+	const uint32_t h = fmix32((uint32_t) (idx ^ (idx >> 32)) + seed * 0x9E3779B9u);
+	if (kind != 0) return h & 255u;
+	const long long num = 1000 * (ax * ax + ayz2);                   // >= 0, < 2^53 for every n <= 65535
+	long long q = (long long) ((double) num * inv_nn);
+	long long r = num - q * nn;
+	if (r < 0) { q--; r += nn; }
+	if (r >= nn) q++;
+	long long t = q - 360;
+	if (t < 0) t = -t;
+	int shell = 255 - (int) (t * 255 / 240);
+	if (shell < 0) shell = 0;
+	const uint32_t v = (uint32_t) shell + (h & 15u);
+	return v > 255u ? 255u : v;
+}
+
 template <int BPV>
 __global__ __launch_bounds__(256)
 void generate_kernel(void *__restrict__ vol, uint32_t kind, uint32_t n, uint32_t seed) {
-	const long long N = n;
-	const uint64_t total = (uint64_t) n * n * n;
+	constexpr uint32_t kPerChunk = 16u / BPV;
+	const long long N = n, nn = N * N;
+	const double inv_nn = 1.0 / (double) nn;
+	const uint64_t total = (uint64_t) n * n * n, chunks = total / kPerChunk;
 	const uint64_t stride = (uint64_t) gridDim.x * 256;
-	for (uint64_t idx = (uint64_t) blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
-		const uint32_t h = fmix32((uint32_t) (idx ^ (idx >> 32)) + seed * 0x9E3779B9u);
-		uint32_t v;
-		if (kind == 0) {
-			const long long x = (long long) (idx % n), y = (long long) ((idx / n) % n), z = (long long) (idx / ((uint64_t) n * n));
-			const long long ax = 2 * x + 1 - N, ay = 2 * y + 1 - N, az = 2 * z + 1 - N;
-			const long long d2 = ax * ax + ay * ay + az * az;
-			long long t = 1000 * d2 / (N * N) - 360;
-			if (t < 0) t = -t;
-			long long shell = 255 - t * 255 / 240;
-			if (shell < 0) shell = 0;
-			v = (uint32_t) shell + (h & 15u);
-			if (v > 255u) v = 255u;
-		} else {
-			v = h & 255u;
+	for (uint64_t c = (uint64_t) blockIdx.x * 256 + threadIdx.x; c < chunks; c += stride) {
+		uint64_t idx = c * kPerChunk;
+		const uint64_t row = idx / n;
+		uint32_t x = (uint32_t) (idx - row * n), y = (uint32_t) (row % n), z = (uint32_t) (row / n);
+		long long ay = 2 * (long long) y + 1 - N, az = 2 * (long long) z + 1 - N, ayz2 = ay * ay + az * az;
+		uint32_t w[4] = { 0u, 0u, 0u, 0u };
+		#pragma unroll
+		for (uint32_t j = 0; j < kPerChunk; j++) {
+			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * (long long) x + 1 - N, ayz2, nn, inv_nn, seed);
+			if (BPV == 1) w[j / 4u] |= v << (8u * (j % 4u)); else w[j / 2u] |= (v * 257u) << (16u * (j % 2u));
+			idx++;
+			if (++x == n) {                                       // next row (and slice)
+				x = 0;
+				if (++y == n) { y = 0; z++; az = 2 * (long long) z + 1 - N; }
+				ay = 2 * (long long) y + 1 - N; ayz2 = ay * ay + az * az;
+			}
 		}
-		if (BPV == 1) ((uint8_t *) vol)[idx] = (uint8_t) v; else ((uint16_t *) vol)[idx] = (uint16_t) (v * 257u);
+		((uint4 *) vol)[c] = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+	if (blockIdx.x == 0) {                                           // fewer than 16 bytes left over
+		for (uint64_t idx = chunks * kPerChunk + threadIdx.x; idx < total; idx += 256) {
+			const uint64_t row = idx / n;
+			const long long x = (long long) (idx - row * n), y = (long long) (row % n), z = (long long) (row / n);
+			const long long ay = 2 * y + 1 - N, az = 2 * z + 1 - N;
+			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * x + 1 - N, ay * ay + az * az, nn, inv_nn, seed);
+			if (BPV == 1) ((uint8_t *) vol)[idx] = (uint8_t) v; else ((uint16_t *) vol)[idx] = (uint16_t) (v * 257u);
+		}
 	}
 }
 

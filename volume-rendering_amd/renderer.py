@@ -161,6 +161,14 @@ class HipRenderer:
         layout policy has at this size).  A refused copy (HBM guard) raises VrError(VR_ERR_ALLOC); frames then read the next best."""
         self._check(self._L.vr_hip_prepare(self._ctx, int(copies)), "prepare")
 
+    def download_copy(self, kind):
+        """vr_hip_download_copy (testing aid): the raw bytes of resident brick copy `kind` (bit index of its VR_COPY_* flag)."""
+        n = C.c_uint64()
+        self._check(self._L.vr_hip_download_copy(self._ctx, int(kind), None, 0, C.byref(n)), "download_copy")
+        out = np.empty(n.value, dtype=np.uint8)
+        self._check(self._L.vr_hip_download_copy(self._ctx, int(kind), out.ctypes.data, out.nbytes, None), "download_copy")
+        return out
+
     def release_linear_copy(self):
         """Frees the linear array (feeders / download / layout changes then need a new set_volume); rendering is unaffected."""
         self._check(self._L.vr_hip_release_linear_copy(self._ctx), "release_linear_copy")
