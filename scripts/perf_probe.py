@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--volume", type=int, default=1024)
     ap.add_argument("--viewport", type=int, default=2048)
     ap.add_argument("--views", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--pose", default="", help="instead of --views: 'ax,ay,az[,p]' camera angles in degrees at distance 2 (p = 1: perspective); several separated by ';'")
     ap.add_argument("--mode", default="nooptims")
     ap.add_argument("--sampling", default="trilinear")
     ap.add_argument("--kind", default="shell")
@@ -52,8 +53,10 @@ def main():
     buf = torch.empty((W, W, 4), dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     res, spread, chosen = {}, {}, {}
-    for v in [int(x) for x in a.views.split(",")]:
-        p = scene.frame_params(vr.benchmark_view(W, W, v), samp)
+    poses = [tuple(float(x) for x in q.split(",")) for q in a.pose.split(";") if q]
+    for v in (range(len(poses)) if poses else [int(x) for x in a.views.split(",")]):
+        view = vr.custom_view(W, W, len(poses[v]) > 3 and poses[v][3] != 0, poses[v][:3], 2.0) if poses else vr.benchmark_view(W, W, v)
+        p = scene.frame_params(view, samp)
         for _ in range(4):                                   # builds the brick copy; records the tile costs / builds the launch order or the per-tile copy choice
             r.render_volume_device(p, buf.data_ptr(), stream)
         torch.cuda.synchronize()

@@ -1,0 +1,70 @@
+"""The deterministic safety net of the unclamped march: a library built with -DVR_BOUNDS_CHECK (scripts/build_variant.sh
+bounds "-DVR_BOUNDS_CHECK" -> build_variants/libvr_hip_bounds.so; `make EXTRA=-DVR_BOUNDS_CHECK` builds the same in place) holds every gather
+address of the march against the array it must lie in, every address-table index against its padded table and the tile-cost slot against
+its buffer, and fails the frame with VR_ERR_HIP instead of faulting the GPU.  This test runs the random scenes, the layouts test and a C4
+whole frame per view ONCE with that build in a child process (VR_HIP_LIB): 0 violations — and proves the net is live by halving the bound
+it checks against (VR_BC_SELFTEST=1), which must fail the frame."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "build_variants", "libvr_hip_bounds.so")
+
+CHILD = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch
+vr = importlib.import_module("volume-rendering_amd")
+r = vr.HipRenderer(0)
+n, W = %(n)d, %(w)d
+r.generate_volume("shell", n, seed=1, bytes_per_voxel=%(bpv)d)
+mm = r.volume_minmax()[0]
+scene = vr.Scene().set_volume(dims=(n, n, n), minmax=mm)
+r.set_transfer_fn(scene.tf, scene.esl)
+r.set_window_buffer(W, W)
+frames = 0
+for mode in ("nooptims", "default"):
+    scene.set_modes(esl=(mode == "default"), ray_threshold=(0.95 if mode == "default" else 1.0))
+    for samp in (vr.SAMPLE_TRILINEAR, vr.SAMPLE_NEAREST):
+        for v in range(8):
+            for rep in range(%(reps)d):
+                out = r.render_volume(scene.frame_params(vr.benchmark_view(W, W, v), samp))
+                frames += 1
+print("frames", frames, "covered", int((out[..., 3] != 0).sum()))
+"""
+
+
+def _child(n, w, bpv, reps, extra_env=None):
+    env = dict(os.environ, VR_HIP_LIB=LIB)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "n": n, "w": w, "bpv": bpv, "reps": reps}], capture_output=True, text=True, env=env, timeout=900)
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="build_variants/libvr_hip_bounds.so not built (scripts/build_variant.sh bounds -DVR_BOUNDS_CHECK)")
+def test_bounds_checked_build_finds_no_violation_and_is_live():
+    # BASELINE C4 (1024^3 @ 2048^2: 32-bit offsets at exactly 2^32 bytes, 64-bit run tables), every view, both modes, both samplings, and
+    # a repeated frame each (the measured-cost tile order / recordings of the second and third frame)
+    r = _child(1024, 2048, 1, 3)
+    assert r.returncode == 0 and "frames 96" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # 2-byte voxels: oct bricks / quad bricks behind 64-bit tables
+    r = _child(256, 512, 2, 1)
+    assert r.returncode == 0 and "frames 32" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # the net is live: with the checked size halved the first full-march frame fails with the bounds-check message
+    r = _child(256, 512, 1, 1, {"VR_BC_SELFTEST": "1"})
+    assert r.returncode != 0 and "bounds check" in r.stderr, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="build_variants/libvr_hip_bounds.so not built")
+def test_parity_suite_under_the_bounds_checked_build():
+    """tests/test_gpu_random.py (168 random scenes: ragged volumes, far views, the clamping variant, wide addressing) and the layouts test once
+    with the checked library: every frame still equals the oracle and none reports a violation (a violation fails the frame: VrError)."""
+    env = dict(os.environ, VR_HIP_LIB=LIB)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_random.py"), os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        "-m", "gpu", "-x", "-q", "-k", "random or layouts_agree or u16 or tile_scheduling or long_thin"],
+                       capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -109,21 +109,23 @@ def test_trilinear_whole_frames_equal_the_restatement_c4(vr, gpu, c4):
     # and reads run bricks), both run copies; nothing was refused
     info = gpu.volume_info()
     assert (info.copies & (vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y)) == 27 and info.copies_refused == 0
-    # The oblique orthogonal view in the full march reads BOTH run copies, chosen per block of tiles by measurement: frames 0-3 of its
-    # parameter set run on the copy along z / y / z / y (the last two record tile costs), frames 4 and 5 read the per-block choice (the
-    # 32 cases above cycle the 16 remembered parameter sets: a set either starts at frame 0 again or continues at frame 1).  Every one of them is the
-    # restatement's frame (4.5 GiB copies: 64-bit table addresses).
+    # The oblique orthogonal view in the full march reads BOTH run copies (4.5 GiB each: 64-bit table addresses), every tile picking its
+    # copy from the cube face its block's centre ray enters through — from the FIRST frame of a new view on (round 4: the rule is analytic,
+    # no recording frames).  The round-3 measured choice stays as the validator (vr_hip_set_brick_plane(6): frames 0-3 on one copy each,
+    # the last two recording tile costs, per-block choice from frame 4 on): same image on every frame of either policy.
     for sampling, samp in (("trilinear", vr.SAMPLE_TRILINEAR), ("trilinear_q8", vr.SAMPLE_TRILINEAR_Q8)):
         case = [c for c in _restatement_hash_cases("c4") if c["view"] == 1 and c["mode"] == "nooptims" and c["sampling"] == sampling][0]
         scene.set_modes(esl=False, ray_threshold=1.0)
         p = scene.frame_params(vr.benchmark_view(W, W, 1), samp)
-        layouts = []
-        for frame in range(6):
-            out = gpu.render_volume(p)
-            layouts.append(gpu.last_launch()["layout"])
-            assert fnv1a32(out) == case["fnv"] and int((out[..., 3] != 0).sum()) == case["nonzero_alpha"], (sampling, frame, layouts)
-        full = [2, 3, 2, 3, 6, 6, 6]                          # starts at frame 0, or at frame 1 when the loop above left this set remembered
-        assert layouts in (full[:6], full[1:7]), layouts
+        for plane, expect in ((-1, [6, 6]), (6, [2, 3, 2, 3, 6, 6])):
+            gpu.set_brick_plane(plane)                    # (drops the remembered parameter sets: the measured sequence starts at frame 0)
+            layouts = []
+            for frame in range(len(expect)):
+                out = gpu.render_volume(p)
+                layouts.append(gpu.last_launch()["layout"])
+                assert fnv1a32(out) == case["fnv"] and int((out[..., 3] != 0).sum()) == case["nonzero_alpha"], (sampling, plane, frame, layouts)
+            assert layouts == expect, (plane, layouts)
+        gpu.set_brick_plane(-1)
     scene.set_modes(esl=True, ray_threshold=0.95)
 
 
@@ -140,14 +142,14 @@ def test_partition_concat_equals_whole_frame(vr, gpu, c4):
             split = dmod.FrameSplit(W, W, world, rank)
             parts.append(torch.from_numpy(gpu.render_volume(split.apply(scene.frame_params(view, vr.SAMPLE_TRILINEAR)))))
         assert np.array_equal(split.assemble(torch.stack(parts)).numpy(), whole), world
-    # the oblique orthogonal view: every rank measures and chooses its run copies per block of ITS tiles (frames 4 and 5 of a band set)
+    # the oblique orthogonal view: every rank's tiles choose their run copies analytically (entry face of the block's centre ray, band map included)
     view = vr.benchmark_view(W, W, 1)
     whole = gpu.render_volume(scene.frame_params(view, vr.SAMPLE_TRILINEAR))
     parts = []
     for rank in range(2):
         split = dmod.FrameSplit(W, W, 2, rank)
         p = split.apply(scene.frame_params(view, vr.SAMPLE_TRILINEAR))
-        frames = [gpu.render_volume(p) for _ in range(6)]
+        frames = [gpu.render_volume(p) for _ in range(3)]
         assert gpu.last_launch()["layout"] == 6
         assert all(np.array_equal(f, frames[0]) for f in frames[1:]), rank
         parts.append(torch.from_numpy(frames[-1]))

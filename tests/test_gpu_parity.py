@@ -167,6 +167,9 @@ def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
                         assert np.array_equal(gpu.render_volume(pf), want), (name, label, samp, kd, "measured", frame)
                         seen.append(gpu.last_launch()["layout"])
                     assert clamped or seen == [2, 3, 2, 3, 6, 6], seen
+                    # the product's rule: every tile picks its copy from the entry face of its block's centre ray, first frame included
+                    gpu.set_brick_plane(-1)
+                    assert np.array_equal(gpu.render_volume(pf), want), (name, label, samp, kd, "analytic")
             gpu.set_brick_plane(-1)
 
 

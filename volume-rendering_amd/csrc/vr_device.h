@@ -66,6 +66,19 @@ struct RayKernelArgs {
 	uint32_t force_wide;               // testing aid: 1 = arithmetic 64-bit path, 2 = 64-bit table path, even for small volumes
 	uint32_t nbx, nby, nbz;            // bricks per axis (bricked layout)
 	uint64_t alt_copy;                 // kLayoutRunDual: address of the run copy along y (the kernel's `vol` argument is the copy along z)
+	uint32_t dual_analytic;            // kLayoutRunDual: 1 = every tile picks its run copy from dual_bits (no launch-order entry needed)
+	uint32_t dual_shift;               // ... one bit per group of (1 << dual_shift) consecutive tile NUMBERS (>= 6: 64 numbers = one 8x8-tile block of the numbering)
+	uint32_t dual_bits[32];            // ... bit set = the block's tiles read the copy with runs along y (vr_hip_api.cpp dual_choice_bits)
+#ifdef VR_BOUNDS_CHECK
+	// `make EXTRA=-DVR_BOUNDS_CHECK` (debug build, not the product): every gather address of the march is held against the array it must
+	// lie in, every address-table index against its padded table, the tile-cost slot against its buffer; the first violation is recorded
+	// in bc_fault[0..5] = { code, workgroup, thread, value lo, value hi, limit } and the access is redirected to the start of the array,
+	// so the frame completes and the launch returns VR_ERR_HIP instead of faulting the GPU.
+	uint64_t bc_base, bc_bytes;        // the array `vol` points at (brick copy or linear array incl. tail slack)
+	uint64_t bc_alt_bytes;             // kLayoutRunDual: size of the copy at alt_copy
+	uint32_t *bc_fault;
+	uint32_t bc_ntiles;
+#endif
 };
 // Tiles are numbered in VR_TILE_ORDER x VR_TILE_ORDER blocks (blocks row-major, tiles row-major inside a block, the ragged right /
 // bottom margins after them): consecutive workgroups — which the hardware spreads over the eight XCDs — are screen neighbours.
@@ -133,6 +146,7 @@ struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr;
 //                   along z).  The host measures both copies per tile on the first two frames of a parameter set (vr_hip_api.cpp).
 enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5, kLayoutRunDual = 6 };
 __host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY || layout == (int) kLayoutRunDual; }
+constexpr uint32_t kDualWords = 32;
 constexpr uint32_t kTileAltBit = 0x80000000u;       // kLayoutRunDual: set in a launch-order entry = this tile reads the copy with runs along y
 __host__ __device__ constexpr bool is_brick_table_layout(int layout) { return layout == (int) kLayoutBricked || layout == (int) kLayoutVoxel; }
 constexpr uint32_t kRunLen = 9, kRunBytes = kRunLen * 4, kRunBrickBytes = 64 * kRunBytes;       // 8x8 cell columns per brick

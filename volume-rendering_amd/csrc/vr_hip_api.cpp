@@ -81,6 +81,9 @@ struct vr_ctx {
 	bool oct_always = false;                // vr_hip_set_brick_plane(5): 2-byte voxels read the oct bricks for every view (testing)
 	// feeders scratch
 	uint8_t *minmax = nullptr; unsigned long long *hist = nullptr;
+#ifdef VR_BOUNDS_CHECK
+	uint32_t *bc_fault = nullptr;           // debug build: first out-of-bounds access of a frame (RayKernelArgs::bc_fault)
+#endif
 	// timing
 	EventPair ring[kEventRing]; int ring_head = 0;
 	hipEvent_t aux_start = nullptr, aux_stop = nullptr;
@@ -110,6 +113,7 @@ int fail(vr_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
 	} while (0)
 
 bool copy_possible(const vr_ctx *c, uint32_t kind);
+uint64_t copy_bytes(const vr_ctx *c, uint32_t kind);
 hipError_t drain(vr_ctx *c);
 const void *copy_for(vr_ctx *c, uint32_t kind);
 
@@ -262,6 +266,63 @@ uint32_t choose_tile_mapping(RayKernelArgs &a) {
 	return (uint32_t) ((groups_straddling[0] + groups_straddling[1]) * 1000 / (groups_seen[0] + groups_seen[1]));
 }
 
+// kLayoutRunDual, the product's rule (no history needed): which run copy the tiles of every block of workgroup tiles read, from the
+// cube face the block's centre ray enters through.  All lanes of a wave start ON that face and march in lockstep, so a wave's samples
+// lie in a plane parallel to it, and the runs should be perpendicular to that plane (every lane then walks down its own run, eight
+// steps per 36 bytes): entry through a z face -> runs along z, through a y face -> runs along y, through an x face -> the run axis
+// the march crosses rather than follows.  Measured in round 3 per tile on pose (-45,-45,0): the upper half of the frame (y face) is 25 %
+// cheaper on the copy along y, the lower half (z and x faces) on the copy along z — what this rule gives; vr_hip_set_brick_plane(6)
+// keeps the measured choice as its validator.  Where a block's centre ray misses the cube other tiles of the block are tried; a block
+// that misses everywhere keeps the frame's default.  Blocks are groups of 64 consecutive tile numbers = the 8x8-tile blocks of the tile
+// numbering (larger groups for huge frames: at most 1024 bits travel in the kernel argument).
+void dual_choice_bits(RayKernelArgs &a, const RaymarchPlan &plan, bool default_alt) {
+	const vr_view &v = a.p.view;
+	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
+	uint32_t shift = 6;                                            // 64 consecutive tile numbers = one 8x8-tile block (tile_number_to_xy)
+	while (((ntiles + (1u << shift) - 1u) >> shift) > 32u * kDualWords) shift++;
+	const uint32_t groups = (ntiles + (1u << shift) - 1u) >> shift;
+	const float tile_w = 32.0f, tile_h = 16.0f;                     // the 512-thread workgroup tile of the table-addressed variants
+	const bool across_is_y = std::fabs(v.direction[2] * a.half_z) >= std::fabs(v.direction[1] * a.half_y);   // entry through an x face
+	memset(a.dual_bits, 0, sizeof a.dual_bits);
+	// tuning aid: VR_DUAL_RULE = 3-bit mask, bit f set = tiles entered through a face of axis f (0 x, 1 y, 2 z) read the copy along y
+	static const int rule = [] { const char *e = getenv("VR_DUAL_RULE"); return e ? atoi(e) : -1; }();
+	auto entry_choice = [&](float px, float py, bool &alt) -> bool {          // pixel of the tile grid -> does its ray hit, and which copy
+		const float lxf = std::fmin(std::fmax(px - (float) a.phase_x, 0.0f), (float) (a.p.out_width - 1u));
+		const float lyf = std::fmin(std::fmax(py - (float) a.phase_y, 0.0f), (float) (a.p.out_rows - 1u));
+		const uint32_t ly = (uint32_t) lyf, band = ly / a.p.band_rows;
+		const uint32_t gy = (band * a.p.band_stride + a.p.band_first) * a.p.band_rows + (ly - band * a.p.band_rows);
+		const float fx = (float) ((int) (a.p.x0 + (uint32_t) lxf) - (int) (v.width / 2u)), fy = (float) ((int) gy - (int) (v.height / 2u));
+		float o[3], d[3], k_in[3], k_out[3];
+		for (int i = 0; i < 3; i++) {
+			o[i] = v.perspective ? v.origin[i] : v.origin[i] + v.right_plane[i] * fx + v.up_plane[i] * fy;
+			d[i] = v.perspective ? v.direction[i] + v.right_plane[i] * fx + v.up_plane[i] * fy : v.direction[i];
+			if (d[i] != 0.0f) { const float k1 = (-1.0f - o[i]) / d[i], k2 = (1.0f - o[i]) / d[i]; k_in[i] = std::fmin(k1, k2); k_out[i] = std::fmax(k1, k2); }
+			else { k_in[i] = -3.0e38f; k_out[i] = std::fabs(o[i]) <= 1.0f ? 3.0e38f : -3.0e38f; }
+		}
+		const float kin = std::fmax(std::fmax(k_in[0], k_in[1]), k_in[2]), kout = std::fmin(std::fmin(k_out[0], k_out[1]), k_out[2]);
+		if (!(kin < kout && kout > 0.0f)) return false;
+		const int face = (k_in[2] >= k_in[0] && k_in[2] >= k_in[1]) ? 2 : (k_in[1] >= k_in[0] ? 1 : 0);
+		alt = rule >= 0 ? ((rule >> face) & 1) != 0 : (face == 2 ? true : (face == 1 ? false : across_is_y));
+		return true;
+	};
+	for (uint32_t g = 0; g < groups; g++) {
+		// the centre of the group's tiles first (tile 27 of 64 = column 3, row 3 of an 8x8 block: next to the block's centre), then a spread of the others
+		const uint32_t first = g << shift, count = std::min(1u << shift, ntiles - first);
+		static const uint32_t probe[9] = { 27, 36, 9, 14, 49, 54, 0, 63, 31 };
+		bool alt = default_alt;
+		for (int i = 0; i < 9; i++) {
+			const uint32_t t = first + (uint32_t) (((uint64_t) probe[i] * count) >> 6);
+			uint32_t tx = 0, ty = 0;
+			tile_number_to_xy(t, plan.tiles_x, plan.tiles_y, &tx, &ty);
+			const float cx = ((float) tx + (probe[i] == 27 ? 1.0f : 0.5f)) * tile_w, cy = ((float) ty + (probe[i] == 27 ? 1.0f : 0.5f)) * tile_h;
+			bool a_i;
+			if (entry_choice(cx, cy, a_i)) { alt = a_i; break; }
+		}
+		if (alt) a.dual_bits[g >> 5] |= 1u << (g & 31u);
+	}
+	a.dual_analytic = 1u; a.dual_shift = shift;
+}
+
 int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stream) {
 	RayKernelArgs a;
 	memset(&a, 0, sizeof a);
@@ -403,14 +464,26 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		if (run_if_unaligned && hit->straddle_permille > 150u && copy_possible(c, run_layout == kLayoutRunY ? kCopyRunY : kCopyRunZ)) a.layout = run_layout;
 	}
 	// Per-tile choice between the two run copies (kLayoutRunDual, vr_device.h): full-march frames only (with leaping or early
-	// termination the rays are short and the tile order above is what matters), automatic tile mapping only, never for the clamping
-	// instantiation (its clamp bounds are per axis, and the tile's y / z exchange would have to reach them).
-	int dual_stage = -1;                                 // -1: not a dual frame; 0..3: the four frames before; 4: per-tile choice in use
-	const bool dual_test = c->brick_plane_force == (int) kPlanes + 4;
-	if (dual_candidate && hit != nullptr && is_run_layout(a.layout) && c->tile_scheduling == 1 && !VR_ORDER_ALWAYS && !p->esl && p->ray_threshold >= 1.0f &&
-	    !a.clamp_fetch && c->bpv == 1 && copy_possible(c, kCopyRunZ) && copy_possible(c, kCopyRunY)) {
-		dual_stage = dual_test ? 4 : (int) hit->dual_state;
-		a.layout = dual_stage == 4 ? kLayoutRunDual : ((dual_stage & 1) ? kLayoutRunY : kLayoutRun);
+	// termination the rays are short and the tile order is what matters), never for the clamping instantiation (its clamp bounds are
+	// per axis, and the tile's y / z exchange would have to reach them).  The product's rule is ANALYTIC and needs no earlier frame:
+	// every tile picks its copy in the kernel from the cube face the centre ray of its block of tiles enters through (raymarch_kernel)
+	// — the first frame of a new view already reads the right copies.  vr_hip_set_brick_plane(6) keeps the round-3 MEASURED choice
+	// (frames 0-3 of a parameter set on one copy each, the last two recording tile costs, choice kernel, per-block choice from frame 4 on)
+	// as the validator of that rule; 7 = alternating tiles (testing: the copies meet at tile boundaries all over the frame).
+	bool dual_analytic = false;
+	int dual_stage = -1;                                 // measured / alternating choice only: -1 no; 0..3: the four frames before; 4: per-tile choice in use
+	const bool dual_test = c->brick_plane_force == (int) kPlanes + 4, dual_measured = c->brick_plane_force == (int) kPlanes + 3;
+	if (dual_candidate && is_run_layout(a.layout) && !p->esl && p->ray_threshold >= 1.0f && !a.clamp_fetch && c->bpv == 1 &&
+	    copy_possible(c, kCopyRunZ) && copy_possible(c, kCopyRunY)) {
+		if (dual_test || dual_measured) {
+			if (hit != nullptr && c->tile_scheduling == 1 && !VR_ORDER_ALWAYS) {
+				dual_stage = dual_test ? 4 : (int) hit->dual_state;
+				a.layout = dual_stage == 4 ? kLayoutRunDual : ((dual_stage & 1) ? kLayoutRunY : kLayoutRun);
+			}
+		} else {
+			dual_analytic = true;
+			a.layout = kLayoutRunDual;
+		}
 	}
 	// The copy this frame reads, built now if this is its first use.  A build that is refused (HBM guard, allocation, linear array
 	// released) degrades to the next best resident copy; the image is the same.
@@ -418,7 +491,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	if (a.layout == kLayoutRunDual) {
 		brick_copy = copy_for(c, kCopyRunZ);
 		a.alt_copy = (uint64_t) (uintptr_t) copy_for(c, kCopyRunY);
-		if (brick_copy == nullptr || a.alt_copy == 0) { a.layout = run_layout; dual_stage = -1; brick_copy = nullptr; }
+		if (brick_copy == nullptr || a.alt_copy == 0) { a.layout = run_layout; dual_stage = -1; dual_analytic = false; brick_copy = nullptr; }
 	}
 	if (a.layout != kLayoutLinear && brick_copy == nullptr) {
 		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
@@ -465,6 +538,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// Measured-cost launch order: only where rays differ in length (empty-space leaping or early termination on) — the full
 	// march has no tail to remove and keeps its cache-friendly tile numbering.
 	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
+	if (dual_analytic && a.layout == kLayoutRunDual) dual_choice_bits(a, plan, run_layout == kLayoutRunY);
 	bool record = false;
 	TileSchedule sched;
 	if (hit != nullptr && c->tile_scheduling == 1 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
@@ -540,6 +614,20 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	c->last_launch = vr_launch_info{ a.layout, a.brick_plane, a.lane_map, a.phase_x, a.phase_y, a.clamp_fetch, plan.tiles_x, plan.tiles_y,
 	                                 sched.order != nullptr ? 1u : 0u, hit != nullptr ? hit->straddle_permille : 1000u };
 
+#ifdef VR_BOUNDS_CHECK
+	{   // debug build: what the frame's gathers must stay inside, and where the first violation is recorded
+		if (c->bc_fault == nullptr) { VR_TRY(c, hipMalloc((void **) &c->bc_fault, 8 * sizeof(uint32_t))); VR_TRY(c, hipMemset(c->bc_fault, 0, 8 * sizeof(uint32_t))); }
+		const void *array = plan.reads_linear ? c->vol : brick_copy;
+		a.bc_base = (uint64_t) (uintptr_t) array;
+		a.bc_bytes = plan.reads_linear ? (c->vol_elems + volume_tail_slack(c->dim[0], c->dim[1])) * c->bpv :
+		             copy_bytes(c, a.layout == kLayoutRun || a.layout == kLayoutRunDual ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
+		                           a.layout == kLayoutOct ? kCopyOct : kCopyQuadXY + a.brick_plane);
+		a.bc_alt_bytes = a.alt_copy ? copy_bytes(c, kCopyRunY) : 0;
+		a.bc_fault = c->bc_fault; a.bc_ntiles = ntiles;
+		// self-test of the net itself: VR_BC_SELFTEST=1 halves the size the checks hold the gathers against — a full-march frame must then fail
+		if (const char *e = getenv("VR_BC_SELFTEST")) if (atoi(e) == 1) a.bc_bytes /= 2;
+	}
+#endif
 	EventPair &ev = c->ring[c->ring_head];
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
@@ -547,6 +635,20 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	VR_TRY(c, launch_raymarch(a, c->vol, brick_copy, c->bpv, c->tf, c->esl, dev_rgba, sched, stream));
 	VR_TRY(c, hipEventRecord(ev.stop, stream));
 	ev.pending = true;
+#ifdef VR_BOUNDS_CHECK
+	{
+		uint32_t fault[6] = { 0, 0, 0, 0, 0, 0 };
+		VR_TRY(c, hipStreamSynchronize(stream));
+		VR_TRY(c, hipMemcpy(fault, c->bc_fault, sizeof fault, hipMemcpyDeviceToHost));
+		if (fault[0] != 0u) {
+			char msg[256];
+			snprintf(msg, sizeof msg, "bounds check: code %u (1 table index [axis << 8], 2 offset, 3 address, 4 cost slot) workgroup %u thread %u value 0x%08x%08x limit %u, layout %u",
+			         fault[0], fault[1], fault[2], fault[4], fault[3], fault[5], a.layout);
+			(void) hipMemset(c->bc_fault, 0, 8 * sizeof(uint32_t));
+			return fail(c, VR_ERR_HIP, msg);
+		}
+	}
+#endif
 	if (dual_advance) {                          // behind the frame, on its stream
 		if (dual_stage == 3) VR_TRY(c, launch_tile_choice(hit->cost, hit->order + hit->capacity, hit->order, ntiles, stream));
 		VR_TRY(c, hipEventRecord(hit->order_ready, stream));
@@ -706,6 +808,9 @@ void vr_hip_destroy(vr_ctx *c) {
 	if (c->aux_start) (void) hipEventDestroy(c->aux_start);
 	if (c->aux_stop) (void) hipEventDestroy(c->aux_stop);
 	if (c->cost_map) (void) hipFree(c->cost_map);
+#ifdef VR_BOUNDS_CHECK
+	if (c->bc_fault) (void) hipFree(c->bc_fault);
+#endif
 	for (auto &e : c->map_cache) { if (e.cost) (void) hipFree(e.cost); if (e.order) (void) hipFree(e.order); if (e.order_ready) (void) hipEventDestroy(e.order_ready); }
 	if (c->fb) (void) hipFree(c->fb);
 	if (c->tf) (void) hipFree(c->tf);

@@ -73,6 +73,44 @@ template <int BPV> struct VoxelT;
 template <> struct VoxelT<1> { typedef uint8_t type; };
 template <> struct VoxelT<2> { typedef uint16_t type; };
 
+// ---- bounds-checked debug build (make EXTRA=-DVR_BOUNDS_CHECK; see RayKernelArgs) -----------------------------------------------
+#ifdef VR_BOUNDS_CHECK
+enum : uint32_t { kBcTableIndex = 1, kBcOffset = 2, kBcAddress = 3, kBcCostSlot = 4 };
+__shared__ uint32_t bc_table_entries[3];       // entries of the x / y / z address tables as staged by this workgroup (dim + 2 * kLutPad)
+__device__ __forceinline__ void bc_report(const RayKernelArgs &a, uint32_t code, uint64_t value, uint64_t limit) {
+	if (atomicCAS(a.bc_fault, 0u, code) == 0u) {
+		a.bc_fault[1] = blockIdx.x; a.bc_fault[2] = threadIdx.x; a.bc_fault[3] = (uint32_t) value; a.bc_fault[4] = (uint32_t) (value >> 32); a.bc_fault[5] = (uint32_t) limit;
+	}
+}
+// table index i (cell coordinate, -kLutPad .. dim - 1 + kLutPad) of table `axis` (0 x, 1 y, 2 z as STAGED: the run axis is "z")
+__device__ __forceinline__ int bc_index(const RayKernelArgs &a, uint32_t axis, int i) {
+	const uint32_t entry = (uint32_t) (i + kLutPad);
+	if (entry < bc_table_entries[axis]) return i;
+	bc_report(a, kBcTableIndex + (axis << 8), (uint64_t) (int64_t) i, bc_table_entries[axis]);
+	return 0;
+}
+__device__ __forceinline__ uint32_t bc_offset(const RayKernelArgs &a, uint32_t offset, uint32_t bytes) {
+	if ((uint64_t) offset + bytes <= a.bc_bytes) return offset;
+	bc_report(a, kBcOffset, offset, a.bc_bytes);
+	return 0u;
+}
+__device__ __forceinline__ uint64_t bc_address(const RayKernelArgs &a, uint64_t address, uint32_t bytes) {
+	if (address >= a.bc_base && address + bytes <= a.bc_base + a.bc_bytes) return address;
+	if (a.alt_copy != 0ull && address >= a.alt_copy && address + bytes <= a.alt_copy + a.bc_alt_bytes) return address;
+	bc_report(a, kBcAddress, address, a.bc_bytes);
+	return a.bc_base;
+}
+#define VR_BC_INDEX(a, axis, i) bc_index((a), (axis), (i))
+#define VR_BC_OFFSET(a, offset, bytes) bc_offset((a), (offset), (bytes))
+#define VR_BC_ADDRESS(a, address, bytes) bc_address((a), (uint64_t) (address), (bytes))
+#define VR_BC_POINTER(a, T, pointer, bytes) ((T) (uintptr_t) bc_address((a), (uint64_t) (uintptr_t) (pointer), (bytes)))
+#else
+#define VR_BC_INDEX(a, axis, i) (i)
+#define VR_BC_OFFSET(a, offset, bytes) (offset)
+#define VR_BC_ADDRESS(a, address, bytes) (address)
+#define VR_BC_POINTER(a, T, pointer, bytes) (pointer)
+#endif
+
 // ---- volume fetch --------------------------------------------------------------------------------------------
 
 // "Managed" gathers of the software-pipelined march: issued through inline asm, so the compiler's s_waitcnt insertion does not
@@ -111,13 +149,15 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 	typedef typename VoxelT<BPV>::type V;
 	if (is_brick_table_layout(LAYOUT)) {
 		typedef LutCfg<ADDR> L;                      // table lookups take indices -kLutPad .. dim - 1 + kLutPad
+		ix = VR_BC_INDEX(a, 0, ix); iy = VR_BC_INDEX(a, 1, iy); iz = VR_BC_INDEX(a, 2, iz);
 		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
 		const uint8_t *q;
+		constexpr uint32_t kBytes = LAYOUT == kLayoutVoxel ? BPV : 4u;       // what the load below reads
 		if (ADDR == kAddr32) {
 			if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 				uint32_t word;
-				if (LAYOUT == kLayoutVoxel) managed_load8(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
-				else managed_load32(word, exy + lut[(int) L::z_words * (iz + kLutPad)], vol);
+				if (LAYOUT == kLayoutVoxel) managed_load8(word, VR_BC_OFFSET(a, exy + lut[(int) L::z_words * (iz + kLutPad)], kBytes), vol);
+				else managed_load32(word, VR_BC_OFFSET(a, exy + lut[(int) L::z_words * (iz + kLutPad)], kBytes), vol);
 				return word;
 			}
 			q = (const uint8_t *) vol + (exy + lut[(int) L::z_words * (iz + kLutPad)]);
@@ -125,6 +165,7 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 			const uint2 z = *(const uint2 *) (lut + (int) L::z_words * (iz + kLutPad));
 			q = (const uint8_t *) vol + ((((uint64_t) z.y) << 32 | z.x) + exy);
 		}
+		q = VR_BC_POINTER(a, const uint8_t *, q, kBytes);
 		// the RAW element word: the voxel is its low byte / half (voxel_of).  Masking here would hand the compiler an operation on the
 		// loaded value that it hoists to the loop latch of the software-pipelined march — behind an s_waitcnt vmcnt(0) that drains
 		// every prefetch once per iteration (measured: the NEAREST full march was latency bound because of it).
@@ -133,10 +174,10 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 	}
 	if (ADDR == kAddrWide) {
 		uint64_t idx = ((uint64_t) iz * a.dim_y + iy) * a.dim_x + ix;
-		return ((const V *) vol)[idx];
+		return *VR_BC_POINTER(a, const V *, (const V *) vol + idx, (uint32_t) sizeof(V));
 	} else {
 		uint32_t idx = (iz * a.dim_y + iy) * a.dim_x + ix;
-		return ((const V *) vol)[idx];
+		return *VR_BC_POINTER(a, const V *, (const V *) vol + idx, (uint32_t) sizeof(V));
 	}
 }
 
@@ -210,7 +251,11 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		yb = __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y);
 		zb = __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
 	}
-	const int ix = (int) xb, iy = (int) yb, iz = (int) zb;          // table layouts: -kLutPad .. dim - 1 + kLutPad are valid
+	int ix = (int) xb, iy = (int) yb, iz = (int) zb;                // table layouts: -kLutPad .. dim - 1 + kLutPad are valid
+	if (LAYOUT != kLayoutLinear && ADDR != kAddrWide) {             // (debug build: each index against the table it is about to address)
+		const bool run_y = LAYOUT == kLayoutRunY;
+		ix = VR_BC_INDEX(a, 0, ix); iy = VR_BC_INDEX(a, run_y ? 2 : 1, iy); iz = VR_BC_INDEX(a, run_y ? 1 : 2, iz);
+	}
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
 	if (is_run_layout(LAYOUT)) {
 		// run bricks: two tables hold the cell column's offset, the third the ABSOLUTE 64-bit address of (brick slab, run coordinate
@@ -220,7 +265,7 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		const int irun = LAYOUT == kLayoutRunY ? iy : iz, iother = LAYOUT == kLayoutRunY ? iz : iy;
 		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iother];
 		const uint2 zz = *(const uint2 *) (lut + 2 * (irun + kLutPad));
-		const uint64_t address = (((uint64_t) zz.y) << 32 | zz.x) + exy;
+		const uint64_t address = VR_BC_ADDRESS(a, (((uint64_t) zz.y) << 32 | zz.x) + exy, 8u);
 		if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 			managed_load64(f.q, address);
 		} else {
@@ -234,6 +279,7 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 		uint64_t address;
 		if (ADDR == kAddr32) address = (uint64_t) (uintptr_t) vol + (uint64_t) (exy + lut[(int) L::z_words * (iz + kLutPad)]);
 		else { const uint2 zz = *(const uint2 *) (lut + (int) L::z_words * (iz + kLutPad)); address = (uint64_t) (uintptr_t) vol + ((((uint64_t) zz.y) << 32 | zz.x) + exy); }
+		address = VR_BC_ADDRESS(a, address, 16u);
 		if (MANAGED && ManagedTri<BPV, ADDR, LAYOUT>::value) managed_load128(f.o, address);
 		else { const uint4 v = *(const uint4 *) address; f.w0 = v.x; f.w1 = v.y; f.w2 = v.z; f.w3 = v.w; }
 	} else if (LAYOUT == kLayoutBricked) {
@@ -259,6 +305,7 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 				q1 = (const uint8_t *) vol + ((((uint64_t) zz.w) << 32 | zz.z) + exy);
 			}
 		}
+		q0 = VR_BC_POINTER(a, const uint8_t *, q0, kElem); q1 = VR_BC_POINTER(a, const uint8_t *, q1, kElem);
 		if (BPV == 1 && MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 			managed_load32(f.w0, (uint32_t) (q0 - (const uint8_t *) vol), vol);
 			managed_load32(f.w1, (uint32_t) (q1 - (const uint8_t *) vol), vol);
@@ -285,6 +332,8 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 			p00 = (const uint8_t *) vol + e;
 			p10 = (const uint8_t *) vol + (e + sy); p01 = (const uint8_t *) vol + (e + sz); p11 = (const uint8_t *) vol + (e + sz + sy);
 		}
+		p00 = VR_BC_POINTER(a, const uint8_t *, p00, 2u * BPV); p10 = VR_BC_POINTER(a, const uint8_t *, p10, 2u * BPV);
+		p01 = VR_BC_POINTER(a, const uint8_t *, p01, 2u * BPV); p11 = VR_BC_POINTER(a, const uint8_t *, p11, 2u * BPV);
 		if (BPV == 1) {
 			uint16_t h0, h1, h2, h3;
 			__builtin_memcpy(&h0, p00, 2); __builtin_memcpy(&h1, p10, 2); __builtin_memcpy(&h2, p01, 2); __builtin_memcpy(&h3, p11, 2);
@@ -463,6 +512,57 @@ template <int I> __device__ __forceinline__ void managed_wait() {       // s_wai
 	asm volatile("s_waitcnt vmcnt(%0)" : : "n"(I));
 }
 
+// -- workgroup -> tile map, chosen by measurement on the 8-XCD chip (scripts/gpu_variants.sh, lit full march, 8-view
+//    mean).  Tiles are numbered in BxB-tile blocks (B = 8: 256x128 pixels), so the ~1000 workgroups in flight at any time
+//    cover a compact screen region and share bricks in both screen directions (row-major numbering: +3..7 %).  Workgroups
+//    are dealt round-robin over the XCDs (b and b + 8 share an L2); three assignments of tiles to XCDs were measured:
+//      0  tile = workgroup id — every block is spread over all eight XCDs (XCD x renders column x of each block)   4.66 ms
+//      1  each XCD owns one contiguous eighth of the tile list (one screen band per L2)                            6.25 ms
+//      2  each XCD owns whole blocks, interleaved over the frame                                                   6.06 ms
+//    Concentrating a compact brick region on ONE L2 (1, 2) is markedly slower than letting all eight L2s serve it —
+//    the reuse between neighbouring tiles is small (the quad elements already carry the +1 neighbours) and a compact
+//    region exercises few L2 channels — so the plain interleave (0) is the default.  Placement affects speed only.
+#ifndef VR_XCD_MODE
+#define VR_XCD_MODE 0
+#endif
+constexpr uint32_t kTileBlock = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
+// tile number (the launch-order entry, or the workgroup id `bid`) -> workgroup tile column / row
+__device__ __forceinline__ void tile_to_xy(uint32_t tiles_x, uint32_t tiles_y, uint32_t tile, uint32_t bid, uint32_t &tile_x, uint32_t &tile_y) {
+	constexpr uint32_t B = kTileBlock;
+	const uint32_t ntiles = tiles_x * tiles_y;
+	const uint32_t full_cols = tiles_x / B, full_rows = tiles_y / B;
+	const uint32_t nblocked = full_cols * full_rows * B * B;          // tiles that lie in complete BxB blocks
+	if (VR_XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
+		const uint32_t xcd = bid & 7u, slot = bid >> 3, q = ntiles >> 3, r = ntiles & 7u;
+		tile = xcd * q + (xcd < r ? xcd : r) + slot;
+	} else if (VR_XCD_MODE == 2) {                                    // whole blocks per XCD, interleaved over the frame
+		const uint32_t covered = (nblocked / (8u * B * B)) * (8u * B * B);
+		if (bid < covered) {
+			const uint32_t set = bid / (8u * B * B), within = bid - set * (8u * B * B);
+			tile = (set * 8u + (within & 7u)) * (B * B) + (within >> 3);
+		}
+	}
+	tile_y = tile / tiles_x; tile_x = tile - tile_y * tiles_x;
+	if (B > 1) {
+		if (tile < nblocked) {
+			const uint32_t blk = tile / (B * B), in = tile - blk * (B * B);
+			uint32_t by = blk / full_cols, bx = blk - by * full_cols;
+#ifdef VR_CENTER_FIRST
+			// blocks from the middle of the frame outwards: the long / opaque rays of a centred object start first
+			by = (by & 1u) ? full_rows / 2u - 1u - (by >> 1) : full_rows / 2u + (by >> 1);
+			bx = (bx & 1u) ? full_cols / 2u - 1u - (bx >> 1) : full_cols / 2u + (bx >> 1);
+#endif
+			tile_x = bx * B + in % B; tile_y = by * B + in / B;
+		} else {                                      // ragged right / bottom margins: leftover tiles, row-major
+			uint32_t rest = tile - nblocked;
+			const uint32_t right_w = tiles_x - full_cols * B, right_n = right_w * full_rows * B;
+			if (rest < right_n) { tile_y = rest / right_w; tile_x = full_cols * B + rest % right_w; }
+			else { rest -= right_n; tile_y = full_rows * B + rest / tiles_x; tile_x = rest % tiles_x; }
+		}
+	}
+
+}
+
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
@@ -481,16 +581,31 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	const uint32_t order_entry = tile_order ? tile_order[blockIdx.x] : blockIdx.x;
 	// kLayoutRunDual: bit 31 of the entry selects the tile's copy (runs along y instead of z); it waits in LDS like the rest of the record
 	const uint32_t tile_of_group = LAYOUT == kLayoutRunDual ? (order_entry & ~kTileAltBit) : order_entry;
-	const bool alt_tile = LAYOUT == kLayoutRunDual && (order_entry & kTileAltBit) != 0u;
+	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
+	constexpr uint32_t kThreads = L::threads;
+	// kLayoutRunDual: which of the two run copies this tile reads.  From the launch-order entry (measured choice, testing aid), or —
+	// the product's rule, no history needed — from the bit the HOST set for the tile's group of 64 consecutive tile numbers, i.e. its
+	// 8x8-tile block (RayKernelArgs::dual_bits: the analytic entry-face rule of vr_hip_api.cpp dual_choice_bits).  Read through a laundered pointer to the kernel-argument segment
+	// (`a` is the first argument: offset 0) so that nothing of it stays in scalar registers across the staging code.
+	bool alt_tile = LAYOUT == kLayoutRunDual && (order_entry & kTileAltBit) != 0u;
+	if (LAYOUT == kLayoutRunDual && a.dual_analytic != 0u) {
+		typedef const RayKernelArgs __attribute__((address_space(4))) *ConstArgs;      // constant address space: scalar loads
+		ConstArgs q = (ConstArgs) __builtin_amdgcn_kernarg_segment_ptr();
+		asm volatile("" : "+s"(q));
+		const uint32_t bit = tile_of_group >> q->dual_shift;        // groups of consecutive tile NUMBERS: 64 = one 8x8-tile block of the numbering
+		const uint32_t word = q->dual_bits[(bit >> 5) & (kDualWords - 1u)];
+		alt_tile = __builtin_amdgcn_readfirstlane((int) ((word >> (bit & 31u)) & 1u)) != 0;       // uniform by construction (kernel arguments and the tile number only)
+	}
 	if (threadIdx.x == 0) {
+#ifdef VR_BOUNDS_CHECK
+		if (tile_of_group >= a.bc_ntiles) { bc_report(a, kBcCostSlot, tile_of_group, a.bc_ntiles); tile_cost = nullptr; }
+#endif
 		const uint64_t slot = tile_cost ? (uint64_t) (uintptr_t) (tile_cost + tile_of_group) : 0ull;
 		group_sched[0] = (uint32_t) (__builtin_readcyclecounter() >> 6); group_sched[1] = (uint32_t) slot; group_sched[2] = (uint32_t) (slot >> 32);
 		group_sched[3] = alt_tile ? 1u : 0u;
 	}
-	typedef LutCfg<(LAYOUT != kLayoutLinear ? ADDR : kAddrWide)> L;
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;        // 8-bit filter weights; everything else as TRILINEAR
 	constexpr bool kUseLut = L::max_dim != 0;
-	constexpr uint32_t kThreads = L::threads;
 	__shared__ LdsTables lds;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[L::words];
 #ifdef VR_LDS_PAD          // tuning aid: occupy extra LDS to lower the number of resident workgroups per CU
@@ -512,6 +627,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 			const uint32_t nbo = along_y ? a.nbz : a.nby;
 			const uint64_t slab = (uint64_t) a.nbx * nbo * kRunBrickBytes;
 			const uint64_t copy_base = alt_tile ? a.alt_copy : (uint64_t) (uintptr_t) vol;
+#ifdef VR_BOUNDS_CHECK
+			if (t == 0) { bc_table_entries[0] = nx + 2 * kLutPad; bc_table_entries[1] = no + 2 * kLutPad; bc_table_entries[2] = nr + 2 * kLutPad; }
+#endif
 			for (uint32_t j = t; j < nr + 2 * kLutPad; j += kThreads) {
 				const uint32_t i = cell_of(j, nr);
 				const uint64_t z0 = copy_base + (i >> 3) * slab + (i & 7u) * 4u;
@@ -522,6 +640,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 		} else if (kUseLut) {
 			const uint32_t nx = a.dim_x, ny = a.dim_y, nz = a.dim_z;
 			const uint32_t elem = LAYOUT == kLayoutVoxel ? BPV : (LAYOUT == kLayoutOct ? 8u * BPV : 4u * BPV);   // bytes per element: one voxel, a quad, or the 2x2x2 neighbourhood
+#ifdef VR_BOUNDS_CHECK
+			if (t == 0) { bc_table_entries[0] = nx + 2 * kLutPad; bc_table_entries[1] = ny + 2 * kLutPad; bc_table_entries[2] = nz + 2 * kLutPad; }
+#endif
 			const uint32_t row = a.nbx * kBrickPitch;                        // elements per brick row / slab
 			const uint64_t slab = (uint64_t) a.nby * row;
 			for (uint32_t jj = t; jj < nz + 2 * kLutPad; jj += kThreads) {
@@ -553,53 +674,8 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	}
 	__syncthreads();
 
-	// -- workgroup -> tile map, chosen by measurement on the 8-XCD chip (scripts/gpu_variants.sh, lit full march, 8-view
-	//    mean).  Tiles are numbered in BxB-tile blocks (B = 8: 256x128 pixels), so the ~1000 workgroups in flight at any time
-	//    cover a compact screen region and share bricks in both screen directions (row-major numbering: +3..7 %).  Workgroups
-	//    are dealt round-robin over the XCDs (b and b + 8 share an L2); three assignments of tiles to XCDs were measured:
-	//      0  tile = workgroup id — every block is spread over all eight XCDs (XCD x renders column x of each block)   4.66 ms
-	//      1  each XCD owns one contiguous eighth of the tile list (one screen band per L2)                            6.25 ms
-	//      2  each XCD owns whole blocks, interleaved over the frame                                                   6.06 ms
-	//    Concentrating a compact brick region on ONE L2 (1, 2) is markedly slower than letting all eight L2s serve it —
-	//    the reuse between neighbouring tiles is small (the quad elements already carry the +1 neighbours) and a compact
-	//    region exercises few L2 channels — so the plain interleave (0) is the default.  Placement affects speed only.
-#ifndef VR_XCD_MODE
-#define VR_XCD_MODE 0
-#endif
-	constexpr uint32_t B = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
-	const uint32_t ntiles = a.tiles_x * a.tiles_y;
-	const uint32_t bid = blockIdx.x;
-	const uint32_t full_cols = a.tiles_x / B, full_rows = a.tiles_y / B;
-	const uint32_t nblocked = full_cols * full_rows * B * B;          // tiles that lie in complete BxB blocks
-	uint32_t tile = tile_of_group;                                    // measured-cost launch order, or the workgroup id
-	if (VR_XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
-		const uint32_t xcd = bid & 7u, slot = bid >> 3, q = ntiles >> 3, r = ntiles & 7u;
-		tile = xcd * q + (xcd < r ? xcd : r) + slot;
-	} else if (VR_XCD_MODE == 2) {                                    // whole blocks per XCD, interleaved over the frame
-		const uint32_t covered = (nblocked / (8u * B * B)) * (8u * B * B);
-		if (bid < covered) {
-			const uint32_t set = bid / (8u * B * B), within = bid - set * (8u * B * B);
-			tile = (set * 8u + (within & 7u)) * (B * B) + (within >> 3);
-		}
-	}
-	uint32_t tile_y = tile / a.tiles_x, tile_x = tile - tile_y * a.tiles_x;
-	if (B > 1) {
-		if (tile < nblocked) {
-			const uint32_t blk = tile / (B * B), in = tile - blk * (B * B);
-			uint32_t by = blk / full_cols, bx = blk - by * full_cols;
-#ifdef VR_CENTER_FIRST
-			// blocks from the middle of the frame outwards: the long / opaque rays of a centred object start first
-			by = (by & 1u) ? full_rows / 2u - 1u - (by >> 1) : full_rows / 2u + (by >> 1);
-			bx = (bx & 1u) ? full_cols / 2u - 1u - (bx >> 1) : full_cols / 2u + (bx >> 1);
-#endif
-			tile_x = bx * B + in % B; tile_y = by * B + in / B;
-		} else {                                      // ragged right / bottom margins: leftover tiles, row-major
-			uint32_t rest = tile - nblocked;
-			const uint32_t right_w = a.tiles_x - full_cols * B, right_n = right_w * full_rows * B;
-			if (rest < right_n) { tile_y = rest / right_w; tile_x = full_cols * B + rest % right_w; }
-			else { rest -= right_n; tile_y = full_rows * B + rest / a.tiles_x; tile_x = rest % a.tiles_x; }
-		}
-	}
+	uint32_t tile_x, tile_y;
+	tile_to_xy(a.tiles_x, a.tiles_y, tile_of_group, blockIdx.x, tile_x, tile_y);
 
 	// -- one wavefront = one 8x8 pixel tile; 8 waves = 32x16 pixels, 16 waves = 32x32.  Inside the wave each group of 16
 	//    consecutive lanes is a 4x4-pixel block (not two 8-pixel rows): a compact block keeps the group's samples inside the
@@ -1463,20 +1539,28 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 }
 
 // One thread per 16-byte chunk of the array (16 or 8 consecutive voxels along x, wrapping into the next row / slice), one 16-byte store.
-// The shell's 1000 * d2 / (N * N) is an exact integer quotient (< 12000) formed from a double-precision estimate and corrected by its
-// remainder — the 64-bit integer division it replaces was what the old one-voxel-per-thread kernel spent its time in.
+// The shell's 1000 * d2 / (N * N) is an exact integer quotient (< 12000): a shift where N is a power of two, else formed in DOUBLE
+// precision (every quantity is an integer below 2^53 for n <= 65535, so the fused remainder r = num - q * N^2 is exact and the estimate
+// floor(num / N^2) is corrected by its sign) — the 64-bit integer division it replaces was what the old one-voxel-per-thread kernel
+// spent its time in.  What remains is the murmur finaliser per voxel: the kernel is bound by integer issue, not by HBM.
+// `shift` != 0: n is a power of two, n * n = 1 << shift, and the quotient is a 64-bit multiply and a shift (the benchmark sizes).
+// The shell is zero wherever 1000 * d2 / n^2 lies outside (120, 600): |q - 360| >= 240.
 template <int BPV>
-__device__ __forceinline__ uint32_t synthetic_voxel(uint32_t kind, uint64_t idx, long long ax, long long ayz2, long long nn, double inv_nn, uint32_t seed) {
+__device__ __forceinline__ uint32_t synthetic_voxel(uint32_t kind, uint64_t idx, int ax, uint64_t ayz2, double nn, double inv_nn, uint32_t shift, uint32_t seed) {
 	const uint32_t h = fmix32((uint32_t) (idx ^ (idx >> 32)) + seed * 0x9E3779B9u);
 	if (kind != 0) return h & 255u;
-	const long long num = 1000 * (ax * ax + ayz2);                   // >= 0, < 2^53 for every n <= 65535
-	long long q = (long long) ((double) num * inv_nn);
-	long long r = num - q * nn;
-	if (r < 0) { q--; r += nn; }
-	if (r >= nn) q++;
-	long long t = q - 360;
+	const uint64_t num = 1000ull * ((uint64_t) ((int64_t) ax * ax) + ayz2);   // < 2^53 for every n <= 65535
+	int q;
+	if (shift != 0u) q = (int) (num >> shift);
+	else {
+		double e = __builtin_floor((double) num * inv_nn);
+		const double r = __builtin_fma(-e, nn, (double) num);        // exact remainder of the estimate (every quantity is an integer < 2^53)
+		if (r < 0.0) e -= 1.0; else if (r >= nn) e += 1.0;
+		q = (int) e;
+	}
+	int t = q - 360;
 	if (t < 0) t = -t;
-	int shell = 255 - (int) (t * 255 / 240);
+	int shell = 255 - (int) ((uint32_t) t * 255u / 240u);
 	if (shell < 0) shell = 0;
 	const uint32_t v = (uint32_t) shell + (h & 15u);
 	return v > 255u ? 255u : v;
@@ -1486,25 +1570,27 @@ template <int BPV>
 __global__ __launch_bounds__(256)
 void generate_kernel(void *__restrict__ vol, uint32_t kind, uint32_t n, uint32_t seed) {
 	constexpr uint32_t kPerChunk = 16u / BPV;
-	const long long N = n, nn = N * N;
-	const double inv_nn = 1.0 / (double) nn;
+	const int N = (int) n;
+	const double nn = (double) n * (double) n, inv_nn = 1.0 / nn;
+	const uint32_t shift = (n & (n - 1u)) == 0u ? 2u * (uint32_t) __builtin_ctz(n) : 0u;
 	const uint64_t total = (uint64_t) n * n * n, chunks = total / kPerChunk;
 	const uint64_t stride = (uint64_t) gridDim.x * 256;
 	for (uint64_t c = (uint64_t) blockIdx.x * 256 + threadIdx.x; c < chunks; c += stride) {
 		uint64_t idx = c * kPerChunk;
 		const uint64_t row = idx / n;
 		uint32_t x = (uint32_t) (idx - row * n), y = (uint32_t) (row % n), z = (uint32_t) (row / n);
-		long long ay = 2 * (long long) y + 1 - N, az = 2 * (long long) z + 1 - N, ayz2 = ay * ay + az * az;
+		int64_t ay = 2 * (int64_t) y + 1 - N, az = 2 * (int64_t) z + 1 - N;
+		uint64_t ayz2 = (uint64_t) (ay * ay + az * az);
 		uint32_t w[4] = { 0u, 0u, 0u, 0u };
 		#pragma unroll
 		for (uint32_t j = 0; j < kPerChunk; j++) {
-			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * (long long) x + 1 - N, ayz2, nn, inv_nn, seed);
+			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * (int) x + 1 - N, ayz2, nn, inv_nn, shift, seed);
 			if (BPV == 1) w[j / 4u] |= v << (8u * (j % 4u)); else w[j / 2u] |= (v * 257u) << (16u * (j % 2u));
 			idx++;
 			if (++x == n) {                                       // next row (and slice)
 				x = 0;
-				if (++y == n) { y = 0; z++; az = 2 * (long long) z + 1 - N; }
-				ay = 2 * (long long) y + 1 - N; ayz2 = ay * ay + az * az;
+				if (++y == n) { y = 0; z++; az = 2 * (int64_t) z + 1 - N; }
+				ay = 2 * (int64_t) y + 1 - N; ayz2 = (uint64_t) (ay * ay + az * az);
 			}
 		}
 		((uint4 *) vol)[c] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -1512,9 +1598,9 @@ void generate_kernel(void *__restrict__ vol, uint32_t kind, uint32_t n, uint32_t
 	if (blockIdx.x == 0) {                                           // fewer than 16 bytes left over
 		for (uint64_t idx = chunks * kPerChunk + threadIdx.x; idx < total; idx += 256) {
 			const uint64_t row = idx / n;
-			const long long x = (long long) (idx - row * n), y = (long long) (row % n), z = (long long) (row / n);
-			const long long ay = 2 * y + 1 - N, az = 2 * z + 1 - N;
-			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * x + 1 - N, ay * ay + az * az, nn, inv_nn, seed);
+			const int x = (int) (idx - row * n);
+			const int64_t ay = 2 * (int64_t) (row % n) + 1 - N, az = 2 * (int64_t) (row / n) + 1 - N;
+			const uint32_t v = synthetic_voxel<BPV>(kind, idx, 2 * x + 1 - N, (uint64_t) (ay * ay + az * az), nn, inv_nn, shift, seed);
 			if (BPV == 1) ((uint8_t *) vol)[idx] = (uint8_t) v; else ((uint16_t *) vol)[idx] = (uint16_t) (v * 257u);
 		}
 	}
