@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--extras", default="modes,host,scale,configs,linear,multi",
+    ap.add_argument("--extras", default="modes,first,host,scale,configs,linear,multi,builders",
                     help="N = 1: which extra legs run after the timed region (other modes, host-buffer region, rank simulation, other configs, linear layout, several-device host overhead)")
     ap.add_argument("--cpu-band-rows", type=int, default=96, help="rows per view of the 1-core CPU-baseline sample")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the multi-rank plumbing, nothing is rendered")
@@ -340,14 +340,14 @@ def run_rank(a):
             torch.cuda.synchronize()
 
     def timed_region():
-        # set-up, not a step: four frames per view, whatever --warmup is — the first builds the brick copy the view reads (copies are
-        # built by the first frame that wants them) and touches it once; a view that is not along a volume axis reads BOTH run copies,
-        # chosen per screen tile by measurement: its frames 0-3 run on one copy each, the last two recording what every tile cost
-        # (vr_hip_set_brick_plane in include/vr_hip.h; the measured-cost tile order of the other modes takes two frames the same way)
+        # set-up, not a step: ONE frame per view, whatever --warmup is — it builds the brick copy the view reads (copies are built by the
+        # first frame that wants them; `set_volume.copy_build_ms` lists what each cost) and touches it once.  Nothing else is learned
+        # from earlier frames in the headline's mode: the full march keeps no history (the per-tile choice between the two run copies is
+        # analytic since round 4); in the modes with leaping / early termination a frame launches its tiles in the order the previous
+        # finished frame of that view direction measured (`extras.first_visit` reports what a first frame costs).
         if not a.dry_run:
-            for _ in range(4):
-                for i in range(8):
-                    render(i, 0)
+            for i in range(8):
+                render(i, 0)
             torch.cuda.synchronize()
         for i in range(a.warmup):
             step(i)
@@ -419,7 +419,8 @@ def run_rank(a):
         else:
             mode_txt = {"nooptims": "ESL off, threshold 1.0", "default": "ESL on, threshold 0.95", "ertonly": "ESL off, threshold 0.95"}[a.mode]
             out["config"] = {"workload": f"BASELINE {a.config}: shell {n}^3 u{8 * bpv} (seed 1) @ {W}x{H}, reference's 8 benchmark views cycled, "
-                                         f"mode={a.mode} ({mode_txt}, light_kd 0.6), sampling={a.sampling}",
+                                         f"mode={a.mode} ({mode_txt}, light_kd 0.6), sampling={a.sampling}; repeated-view regime (each view was "
+                                         f"rendered before: copies resident) — extras.first_visit holds the one-frame-per-view / moving-camera figures",
                              "volume": [n, n, n], "viewport": [W, H], "bytes_per_voxel": bpv, "ray_step": float(scene.params.ray_step),
                              "partition": partition}
             # ALGORITHMIC bytes per launch: compulsory HBM traffic = every voxel once + the RGBA8 framebuffer,
@@ -484,6 +485,9 @@ def run_rank(a):
                 if "modes" in legs:      # before the legs that create many streams: a process has 8 hardware queues, later streams share them
                     out["extras"]["two_frames_concurrent"] = bx.concurrent_frames_leg(vr, r, params, local[0])
                 with torch.cuda.stream(render_stream):
+                    if "first" in legs:
+                        out["extras"]["first_visit"] = bx.first_visit_leg(vr, r, scene, W, H, local[0], stream, render_stream.synchronize)
+                        set_mode(scene, a.mode)
                     if "host" in legs:
                         out["extras"]["host_buffer"] = bx.host_buffer_leg(vr, r, scene, views, sampling)
                         out["host_buffer_ms"] = out["extras"]["host_buffer"]["ms_mean"]
@@ -512,6 +516,15 @@ def run_rank(a):
                                                           "4 two-voxel loads per sample — north_star's literal layout, timed beside the product's brick copies"}
                 if "multi" in legs:
                     out["extras"]["multi_overhead"] = bx.multi_overhead(vr, local_rank)
+                if "builders" in legs:
+                    # what set_volume costs, kernel by kernel, each with its own HBM roofline (bytes = linear array read once + copy written once;
+                    # the generator: the array written once) — in a context of its own: generation, then every copy the policy has at this size
+                    import copy_build_probe as cbp
+                    r2 = vr.HipRenderer(local_rank)
+                    try:
+                        out["set_volume"]["builders"] = cbp.probe(vr, r2, n, bpv, reps=2)
+                    finally:
+                        r2.close()
             if world == 1 and not a.no_cpu_baseline and bpv == 1:
                 out["cpu_baseline"] = cpu_baseline(vr, r, scene, views, n, W, H, a.cpu_band_rows)
                 # the comparison north_star asks for, labelled — vs_baseline itself stays null (BASELINE.md has no published number)

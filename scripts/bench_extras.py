@@ -40,6 +40,68 @@ def time_views(r, params, buf, stream, sync, warm=4, reps=3):
     return per_view, sum(per_view) / len(per_view), worst
 
 
+def first_visit_leg(vr, r, scene, W, H, buf, stream, sync, modes=("nooptims", "default"), samplings=("trilinear", "nearest")):
+    """The regime the reference's own benchmark and its interactive loop run in (VolR.cpp:225-248: each of the 8 views ONCE per
+    configuration; VolR.cpp:98-113 / UI.cpp:117-139: a new View every frame) beside the repeated-view regime of the headline.  Copies
+    resident (set-up frames elsewhere have built them), then per mode and sampling:
+      protocol : the 8 benchmark views, each rendered once right after the policy state was dropped (vr_hip_set_tile_scheduling resets it),
+                 four rounds — kernel ms of those FIRST frames, mean / max / per view;
+      moving   : 64 DISTINCT views (every benchmark pose turned by j * (0.4, 0.3, 0) degrees, j = 1..8: no parameter set ever repeats), rendered
+                 back to back — ms per frame, mean / max;
+      steady   : the same 8 + 64 views, each after three earlier identical frames (what the headline's timed region sees).
+    Nothing here depends on an earlier frame with identical parameters except the `steady` figures."""
+    poses = ((0.0, 0.0, 0.0), (-45.0, -45.0, 0.0), (90.0, 0.0, 0.0), (180.0, 90.0, 0.0))
+    exact = [vr.benchmark_view(W, H, i) for i in range(8)]
+    moved = [vr.custom_view(W, H, i >= 4, (poses[i & 3][0] + 0.4 * j, poses[i & 3][1] + 0.3 * j, poses[i & 3][2]), 2.0) for i in range(8) for j in range(1, 9)]
+    code = {"trilinear": vr.SAMPLE_TRILINEAR, "nearest": vr.SAMPLE_NEAREST}
+
+    def once(p):
+        r.timing_reset()
+        r.render_volume_device(p, buf.data_ptr(), stream)
+        sync()
+        return r.timing().kernel_ms
+
+    out = {"what": "first frames (no earlier frame with the same parameters: the reference's one-frame-per-view benchmark protocol, and a camera "
+                   "that moves every frame) against repeated frames; kernel ms (hipEvents); copies already resident"}
+    for mode in modes:
+        set_mode(scene, mode)
+        for sname in samplings:
+            ps_exact = [scene.frame_params(v, code[sname]) for v in exact]
+            ps_moved = [scene.frame_params(v, code[sname]) for v in moved]
+            for p in ps_exact + ps_moved[::8]:                  # copies these views read exist before anything is timed
+                r.render_volume_device(p, buf.data_ptr(), stream)
+            sync()
+            first = [[] for _ in range(8)]
+            for _ in range(4):
+                r.set_tile_scheduling(1)                        # forgets every remembered order / recording
+                for i, p in enumerate(ps_exact):
+                    first[i].append(once(p))
+            steady = []
+            for p in ps_exact:
+                for _ in range(3):
+                    r.render_volume_device(p, buf.data_ptr(), stream)
+                sync()
+                steady.append((once(p) + once(p)) / 2)
+            r.set_tile_scheduling(1)
+            mv = [once(p) for p in ps_moved]
+            mv_steady = []
+            for p in ps_moved[::4]:
+                for _ in range(3):
+                    r.render_volume_device(p, buf.data_ptr(), stream)
+                sync()
+                mv_steady.append(once(p))
+            fm = [sum(x) / len(x) for x in first]
+            out[f"{mode}_{sname}"] = {
+                "protocol_first_ms": round(sum(fm) / 8, 4), "protocol_first_ms_max": round(max(max(x) for x in first), 4),
+                "protocol_first_per_view_ms": [round(x, 4) for x in fm],
+                "protocol_steady_ms": round(sum(steady) / 8, 4), "protocol_steady_per_view_ms": [round(x, 4) for x in steady],
+                "protocol_first_over_steady": round(sum(fm) / sum(steady), 4),
+                "moving_ms": round(sum(mv) / len(mv), 4), "moving_ms_max": round(max(mv), 4),
+                "moving_steady_ms": round(sum(mv_steady) / len(mv_steady), 4),
+                "moving_over_steady": round((sum(mv) / len(mv)) / (sum(mv_steady) / len(mv_steady)), 4)}
+    return out
+
+
 def roofline(alg_bytes, kernel_ms):
     ach = alg_bytes / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg_bytes), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

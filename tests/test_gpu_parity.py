@@ -383,6 +383,53 @@ def test_tile_scheduling_is_placement_only(vr, gpu, oracle):
         gpu.set_tile_scheduling(1)
 
 
+def test_orders_and_recordings_with_frames_in_flight_on_two_streams(vr, gpu, oracle):
+    """buffers of the measured-cost orders must never be rewritten under a frame that is still reading them.  Ordered frames are
+    queued on stream A while stream B — with no host synchronisation in between — renders more new parameter sets than the order cache
+    holds entries (every one records and builds an order; a moving camera), the scheduling state is reset and a copy is prepared on the way.
+    Every frame of both streams equals the oracle's (a permutation read while it is rewritten would leave pixels unwritten)."""
+    import torch
+    vox = oracle.generate_volume("shell", 64, 1)
+    tf, esl, bd, bs, step = oracle.scene_for(vox)
+    gpu.set_transfer_fn(tf, esl)
+    gpu.set_volume(vox)
+    W, H = 500, 333
+    gpu.set_window_buffer(W, H)
+
+    def params(view):
+        p = vr.VrParams()
+        p.view = view
+        p.ray_step, p.ray_threshold, p.esl, p.esl_block_dims, p.light_kd, p.sampling = float(step), 0.95, 1, bd, 0.6, vr.SAMPLE_TRILINEAR
+        for j in range(3):
+            p.esl_block_size[j] = float(bs[j])
+        return vr.whole_frame(p)
+
+    p0 = params(vr.benchmark_view(W, H, 1))
+    want0 = oracle.render(p0, vox, tf, esl)
+    gpu.set_tile_scheduling(1)
+    for _ in range(3):
+        assert np.array_equal(gpu.render_volume(p0), want0)                # recordings, then an ordered frame
+    assert gpu.last_launch()["ordered"] == 1
+    moving = [params(vr.custom_view(W, H, j % 2 == 1, (-45.0 + 9.0 * j, -45.0 + 5.0 * j, 3.0 * j), 2.0)) for j in range(1, 25)]
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    out_a = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in range(12)]
+    out_b = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0") for _ in moving]
+    torch.cuda.synchronize()
+    for i, pj in enumerate(moving):
+        if i % 2 == 0:
+            gpu.render_volume_device(p0, out_a[i // 2].data_ptr(), a.cuda_stream)
+        gpu.render_volume_device(pj, out_b[i].data_ptr(), b.cuda_stream)
+        if i == 9:
+            gpu.set_tile_scheduling(1)                                      # drops every remembered order with frames of both streams in flight
+        if i == 15:
+            gpu.prepare(vr.COPY_QUAD_XZ)
+    torch.cuda.synchronize()
+    for i, t in enumerate(out_a):
+        assert np.array_equal(t.cpu().numpy(), want0), ("stream A frame", i)
+    for i, (t, pj) in enumerate(zip(out_b, moving)):
+        assert np.array_equal(t.cpu().numpy(), oracle.render(pj, vox, tf, esl)), ("stream B frame", i)
+
+
 def test_multi_device_frame_equals_single_device(vr, gpu, golden):
     """vr_hip_multi_*: one call, several per-device contexts, interleaved bands gathered on devices[0] and de-interleaved there.
     On a one-GPU box the list names device 0 once (the single path), twice and three times (band split + peer-copy gather +

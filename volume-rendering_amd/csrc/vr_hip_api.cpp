@@ -59,21 +59,30 @@ struct vr_ctx {
 	uint32_t force_clamp_fetch = 0;              // testing aid (vr_hip_set_wide_addressing bit 2)
 	int32_t  tile_lane_map = -1;                 // -1 = choose per frame (choose_tile_mapping), else forced
 	uint32_t tile_phase_x = 0, tile_phase_y = 0;
-	// the last few automatic choices, keyed by the frame parameters and the volume size (a benchmark cycles 8 views)
-	// Each entry also carries the measured-cost launch order of its frame (vr_kernels.hip tile_order_kernel): the first frame with
-	// these parameters records what every tile cost, the order kernel runs behind it on the same stream, later frames launch their
-	// tiles most expensive first.  order_state: 0 nothing yet, 1 or 2 = `order` is valid for `order_tiles` tiles; the frame that finds
-	// state 1 records once more (the very first frame of a view runs on cold caches and address translations, which makes its early
-	// tiles look expensive) and rebuilds the order behind itself; state 2 is final.
+	// the last few automatic tile mappings (lane order, tile phase), keyed by the frame parameters and the volume size (a benchmark
+	// cycles 8 views).  cost / order / dual_state / order_ready / order_stream serve only the MEASURED run-copy choice
+	// (vr_hip_set_brick_plane(6), the validator of the analytic rule: frames 0 / 1 of a parameter set run on the copy along z / y,
+	// frames 2 / 3 do so again and record their tile costs, the choice kernel behind frame 3 fills order[], frames 4.. read it).
 	struct MapEntry { vr_params p; uint32_t dim[3]; uint32_t lane_map, phase_x, phase_y, straddle_permille;
-	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0, order_state = 0, order_layout = 0;
-	                  // kLayoutRunDual (full-march frames of views that are not along an axis; such frames never use a cost order, so the
-	                  // buffers above are free): frames 0 / 1 of the parameter set run on the copy along z / along y (first touch of each),
-	                  // frames 2 / 3 do so again and record their tile costs (cost[] / second half of order[]), the choice kernel behind
-	                  // frame 3 fills the first half of order[], and from frame 4 on the tiles read the copy that was cheaper for them
+	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0;
 	                  uint32_t dual_state = 0;
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
 	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
+	// Measured-cost launch orders (vr_kernels.hip tile_order_kernel), keyed by what the cost of a tile DEPENDS on — sampling mode,
+	// leaping / termination on or off, projection, the view's major axis, the band partition, the tile grid and the copy read — not by
+	// the byte image of the parameters: a camera that moves keeps its entry, every frame launches its tiles in the order the most recent
+	// FINISHED recording gives and records its own costs for the next one; a frame repeated with identical parameters stops recording
+	// after two (the first may have run on cold caches).  Three slots per entry so that frames in flight on several streams never
+	// share a buffer that is being rewritten: a slot is recycled only once every frame that read or recorded it is known to have
+	// finished (the event ring below) and its order kernel has run (`ready`) — ADVICE r3: no buffer of a frame in flight is touched.
+	struct SchedSlot { uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, ntiles = 0; hipEvent_t ready = nullptr; hipStream_t stream = nullptr;
+	                   uint64_t last_seq = 0, issue_seq = 0; bool valid = false; };
+	struct OrderKey { int32_t direction_q[3]; uint32_t sampling, esl, ert, perspective, major_axis, layout, view_w, view_h, x0, out_width, out_rows, band_rows, band_stride, band_first,
+	                  dim[3], tiles_x, tiles_y; };
+	struct OrderEntry { OrderKey key; bool used = false; SchedSlot slot[3]; vr_params last; bool has_last = false; uint32_t repeats = 0; uint64_t lru = 0; };
+	OrderEntry order_cache[16];
+	uint64_t seq_next = 1, completed_seq = 0;      // frames launched so far + 1; every frame <= completed_seq is known to have finished
+	uint64_t ring_seq[kEventRing] = {};            // the frame whose events sit in ring entry i
 	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order, 2 = cost map
 	vr_launch_info last_launch = {};        // vr_hip_last_launch
 	uint32_t *cost_map = nullptr;           // mode 2: what every tile of the LAST frame cost (vr_hip_read_tile_costs)
@@ -266,15 +275,30 @@ uint32_t choose_tile_mapping(RayKernelArgs &a) {
 	return (uint32_t) ((groups_straddling[0] + groups_straddling[1]) * 1000 / (groups_seen[0] + groups_seen[1]));
 }
 
+// Moves c->completed_seq forward over every frame whose stop event has been reached (frames complete out of order across streams:
+// the mark only passes a frame once all earlier ones are done too — conservative, which is what recycling a buffer needs).
+void advance_completed(vr_ctx *c) {
+	while (c->completed_seq + 1 < c->seq_next) {
+		const uint64_t next = c->completed_seq + 1;
+		const int slot = (int) ((c->ring_head + kEventRing - (int) ((c->seq_next - next) % kEventRing)) % kEventRing);
+		if (c->seq_next - next < (uint64_t) kEventRing && c->ring_seq[slot] == next && c->ring[slot].pending) {
+			const hipError_t q = hipEventQuery(c->ring[slot].stop);
+			if (q != hipSuccess) { (void) hipGetLastError(); break; }
+		}                                            // (an entry that was overwritten or harvested since belongs to a finished frame)
+		c->completed_seq = next;
+	}
+}
+
 // kLayoutRunDual, the product's rule (no history needed): which run copy the tiles of every block of workgroup tiles read, from the
 // cube face the block's centre ray enters through.  All lanes of a wave start ON that face and march in lockstep, so a wave's samples
-// lie in a plane parallel to it, and the runs should be perpendicular to that plane (every lane then walks down its own run, eight
-// steps per 36 bytes): entry through a z face -> runs along z, through a y face -> runs along y, through an x face -> the run axis
-// the march crosses rather than follows.  Measured in round 3 per tile on pose (-45,-45,0): the upper half of the frame (y face) is 25 %
-// cheaper on the copy along y, the lower half (z and x faces) on the copy along z — what this rule gives; vr_hip_set_brick_plane(6)
-// keeps the measured choice as its validator.  Where a block's centre ray misses the cube other tiles of the block are tried; a block
-// that misses everywhere keeps the frame's default.  Blocks are groups of 64 consecutive tile numbers = the 8x8-tile blocks of the tile
-// numbering (larger groups for huge frames: at most 1024 bits travel in the kernel argument).
+// lie in a plane parallel to it: the runs should lie IN that plane (lanes that are neighbours along the run axis then read the same
+// 36-byte run, and the wave touches fewer lines per step) — entry through a z face -> runs along y, through a y face -> runs along z,
+// through an x face -> runs along y.  Measured (scripts/gpu_r04_c.sh, full march, four oblique orthogonal poses, ms): this rule 2.76 /
+// 2.88 / 2.82 / 2.99; the round-3 MEASURED per-block choice (four set-up frames per parameter set) 2.80 / 2.94 / 2.88 / 2.96; one copy
+// for the whole frame 3.18-3.54; the other seven face -> copy tables 2.85-4.0 (x face -> runs along z: 2.85 / 2.86 / 3.05 / 2.95).
+// vr_hip_set_brick_plane(6) keeps the measured choice as the validator.  Where a block's centre ray misses the cube other tiles of
+// the block are tried; a block that misses everywhere keeps the frame's default.  Blocks are groups of 64 consecutive tile numbers =
+// the 8x8-tile blocks of the tile numbering (larger groups for huge frames: at most 1024 bits travel in the kernel argument).
 void dual_choice_bits(RayKernelArgs &a, const RaymarchPlan &plan, bool default_alt) {
 	const vr_view &v = a.p.view;
 	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
@@ -282,7 +306,6 @@ void dual_choice_bits(RayKernelArgs &a, const RaymarchPlan &plan, bool default_a
 	while (((ntiles + (1u << shift) - 1u) >> shift) > 32u * kDualWords) shift++;
 	const uint32_t groups = (ntiles + (1u << shift) - 1u) >> shift;
 	const float tile_w = 32.0f, tile_h = 16.0f;                     // the 512-thread workgroup tile of the table-addressed variants
-	const bool across_is_y = std::fabs(v.direction[2] * a.half_z) >= std::fabs(v.direction[1] * a.half_y);   // entry through an x face
 	memset(a.dual_bits, 0, sizeof a.dual_bits);
 	// tuning aid: VR_DUAL_RULE = 3-bit mask, bit f set = tiles entered through a face of axis f (0 x, 1 y, 2 z) read the copy along y
 	static const int rule = [] { const char *e = getenv("VR_DUAL_RULE"); return e ? atoi(e) : -1; }();
@@ -302,7 +325,7 @@ void dual_choice_bits(RayKernelArgs &a, const RaymarchPlan &plan, bool default_a
 		const float kin = std::fmax(std::fmax(k_in[0], k_in[1]), k_in[2]), kout = std::fmin(std::fmin(k_out[0], k_out[1]), k_out[2]);
 		if (!(kin < kout && kout > 0.0f)) return false;
 		const int face = (k_in[2] >= k_in[0] && k_in[2] >= k_in[1]) ? 2 : (k_in[1] >= k_in[0] ? 1 : 0);
-		alt = rule >= 0 ? ((rule >> face) & 1) != 0 : (face == 2 ? true : (face == 1 ? false : across_is_y));
+		alt = rule >= 0 ? ((rule >> face) & 1) != 0 : face != 1;
 		return true;
 	};
 	for (uint32_t g = 0; g < groups; g++) {
@@ -450,7 +473,9 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			const uint32_t straddle = choose_tile_mapping(a);
 			hit = &c->map_cache[c->map_next];
 			hit->straddle_permille = straddle;
-			hit->order_state = 0;                        // the recycled entry's launch order belonged to other parameters
+			// the recycled entry's measured copy choice belonged to other parameters; frames that read or record its buffers may still be
+			// in flight on other streams — the validator is a testing aid, so it simply waits for them
+			if (hit->dual_state != 0 || hit->order_tiles != 0) VR_TRY(c, drain(c));
 			hit->dual_state = 0; hit->order_tiles = 0;
 			c->map_next = (c->map_next + 1) % 16u;
 			if (c->map_cached < 16u) c->map_cached++;
@@ -539,29 +564,71 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// march has no tail to remove and keeps its cache-friendly tile numbering.
 	const uint32_t ntiles = plan.tiles_x * plan.tiles_y;
 	if (dual_analytic && a.layout == kLayoutRunDual) dual_choice_bits(a, plan, run_layout == kLayoutRunY);
-	bool record = false;
 	TileSchedule sched;
-	if (hit != nullptr && c->tile_scheduling == 1 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
-		if (hit->order_state >= 1 && (hit->order_tiles != ntiles || hit->order_layout != a.layout)) hit->order_state = 0;   // another copy / tile size since
-		if (hit->order_state >= 1) {
-			// built on another stream: this frame must not read the order before the kernel that writes it has run
-			if (stream != hit->order_stream) VR_TRY(c, hipStreamWaitEvent(stream, hit->order_ready, 0));
-			// the second order lives in the second half of the buffer: a frame still running on another stream keeps reading the first
-			sched.order = hit->order + (hit->order_state == 2 ? hit->capacity : 0u);
-			if (hit->order_state == 1 && stream == hit->order_stream) {      // second recording, under the first order (the order kernel cleared cost[])
-				sched.cost = hit->cost;
-				record = true;
+	vr_ctx::SchedSlot *read_slot = nullptr, *record_slot = nullptr;
+	vr_ctx::OrderEntry *oe = nullptr;
+	if (c->tile_scheduling == 1 && c->tile_lane_map < 0 && (VR_ORDER_ALWAYS || p->esl || p->ray_threshold < 1.0f) && ntiles >= 64 && ntiles <= (1u << 20)) {
+		advance_completed(c);
+		vr_ctx::OrderKey key;
+		memset(&key, 0, sizeof key);
+		key.sampling = p->sampling; key.esl = p->esl ? 1u : 0u; key.ert = p->ray_threshold < 1.0f ? 1u : 0u; key.perspective = p->view.perspective ? 1u : 0u;
+		{
+			const float dx = std::fabs(p->view.direction[0] * a.half_x), dy = std::fabs(p->view.direction[1] * a.half_y), dz = std::fabs(p->view.direction[2] * a.half_z);
+			const int m = dz >= dx && dz >= dy ? 2 : (dy >= dx ? 1 : 0);
+			key.major_axis = (uint32_t) m * 2u + (p->view.direction[m] < 0.0f ? 1u : 0u);
+			// ... and the direction itself in steps of 1/8 per component (views within a few degrees share their costs, different poses do not)
+			const float len = std::sqrt(p->view.direction[0] * p->view.direction[0] + p->view.direction[1] * p->view.direction[1] + p->view.direction[2] * p->view.direction[2]);
+			for (int i = 0; i < 3; i++) key.direction_q[i] = len > 0.0f ? (int32_t) std::lrint(p->view.direction[i] / len * 8.0f) : 0;
+		}
+		key.layout = a.layout; key.view_w = p->view.width; key.view_h = p->view.height; key.x0 = p->x0; key.out_width = p->out_width; key.out_rows = p->out_rows;
+		key.band_rows = p->band_rows; key.band_stride = p->band_stride; key.band_first = p->band_first;
+		memcpy(key.dim, c->dim, sizeof key.dim); key.tiles_x = plan.tiles_x; key.tiles_y = plan.tiles_y;
+		vr_ctx::OrderEntry *lru = &c->order_cache[0];        // an unused entry if there is one, else the least recently used
+		for (auto &e : c->order_cache) {
+			if (e.used && memcmp(&e.key, &key, sizeof key) == 0) { oe = &e; break; }
+			if (lru->used && (!e.used || e.lru < lru->lru)) lru = &e;
+		}
+		if (oe == nullptr) {                         // new policy key: take the least recently used entry; its slots keep their buffers and their last-use marks
+			oe = lru;
+			oe->used = true; oe->key = key; oe->has_last = false; oe->repeats = 0;
+			for (auto &sl : oe->slot) sl.valid = false;
+		}
+		oe->lru = c->seq_next;
+		// the order this frame launches in: the most recently issued one that has FINISHED (or was issued on this very stream, which orders it
+		// before this frame); only when there is none, one still being built on another stream, behind a device-side wait
+		vr_ctx::SchedSlot *pending_elsewhere = nullptr;
+		for (auto &sl : oe->slot) {
+			if (!sl.valid || sl.ntiles != ntiles) continue;
+			bool usable = sl.stream == stream;
+			if (!usable) { const hipError_t q = hipEventQuery(sl.ready); if (q == hipSuccess) usable = true; else (void) hipGetLastError(); }
+			if (usable) { if (read_slot == nullptr || sl.issue_seq > read_slot->issue_seq) read_slot = &sl; }
+			else if (pending_elsewhere == nullptr || sl.issue_seq > pending_elsewhere->issue_seq) pending_elsewhere = &sl;
+		}
+		if (read_slot == nullptr && pending_elsewhere != nullptr) {
+			VR_TRY(c, hipStreamWaitEvent(stream, pending_elsewhere->ready, 0));
+			read_slot = pending_elsewhere;
+		}
+		if (read_slot != nullptr) sched.order = read_slot->order;
+		// record this frame's tile costs?  Always while the parameters keep changing (a moving camera: the next frame's order comes from
+		// this one), twice for a frame that is repeated unchanged (the first recording of a view may have run on cold caches)
+		const bool same = oe->has_last && memcmp(&oe->last, p, sizeof *p) == 0;
+		if (!same) { oe->last = *p; oe->has_last = true; oe->repeats = 0; }
+		if (oe->repeats < 2u) {
+			for (auto &sl : oe->slot) {
+				if (&sl == read_slot || sl.last_seq > c->completed_seq) continue;                     // in use by this frame / by a frame that may still run
+				if (sl.ready != nullptr && sl.issue_seq != 0) { const hipError_t q = hipEventQuery(sl.ready); if (q != hipSuccess) { (void) hipGetLastError(); continue; } }   // its order kernel has not run yet
+				if (record_slot == nullptr || (!sl.valid && record_slot->valid) || (sl.valid == record_slot->valid && sl.issue_seq < record_slot->issue_seq)) record_slot = &sl;
 			}
-		} else {
-			if (hit->capacity < ntiles) {
-				if (hit->cost) { VR_TRY(c, drain(c)); (void) hipFree(hit->cost); (void) hipFree(hit->order); hit->cost = hit->order = nullptr; hit->capacity = 0; }
-				if (hipMalloc((void **) &hit->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &hit->order, (size_t) ntiles * 8) == hipSuccess) hit->capacity = ntiles;
-				else { (void) hipGetLastError(); if (hit->cost) (void) hipFree(hit->cost); hit->cost = hit->order = nullptr; }
+			if (record_slot != nullptr && record_slot->capacity < ntiles) {                        // (free: nothing of it is in flight)
+				if (record_slot->cost) { (void) hipFree(record_slot->cost); (void) hipFree(record_slot->order); record_slot->cost = record_slot->order = nullptr; record_slot->capacity = 0; }
+				if (hipMalloc((void **) &record_slot->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &record_slot->order, (size_t) ntiles * 4) == hipSuccess) record_slot->capacity = ntiles;
+				else { (void) hipGetLastError(); if (record_slot->cost) (void) hipFree(record_slot->cost); record_slot->cost = record_slot->order = nullptr; record_slot = nullptr; }
 			}
-			if (hit->capacity >= ntiles) {
-				VR_TRY(c, hipMemsetAsync(hit->cost, 0, (size_t) ntiles * 4, stream));
-				sched.cost = hit->cost;
-				record = true;
+			if (record_slot != nullptr) {
+				if (record_slot->ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&record_slot->ready, hipEventDisableTiming));
+				record_slot->valid = false;
+				VR_TRY(c, hipMemsetAsync(record_slot->cost, 0, (size_t) ntiles * 4, stream));
+				sched.cost = record_slot->cost;
 			}
 		}
 	}
@@ -629,6 +696,8 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 #endif
 	EventPair &ev = c->ring[c->ring_head];
+	const uint64_t frame_seq = c->seq_next++;
+	c->ring_seq[c->ring_head] = frame_seq;
 	c->ring_head = (c->ring_head + 1) % kEventRing;
 	harvest(c, ev);                              // only blocks if 256 launches are still in flight
 	VR_TRY(c, hipEventRecord(ev.start, stream));
@@ -655,11 +724,12 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		hit->order_stream = stream; hit->order_tiles = ntiles;
 		hit->dual_state = (uint32_t) dual_stage + 1u;
 	}
-	if (record) {                                // behind the frame, on its stream: the next frame with these parameters is ordered
-		VR_TRY(c, launch_tile_order(hit->cost, hit->order + (hit->order_state == 0 ? 0u : hit->capacity), ntiles, stream));
-		if (hit->order_ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&hit->order_ready, hipEventDisableTiming));
-		VR_TRY(c, hipEventRecord(hit->order_ready, stream));
-		hit->order_state = hit->order_state == 0 ? 1 : 2; hit->order_tiles = ntiles; hit->order_layout = a.layout; hit->order_stream = stream;
+	if (read_slot != nullptr) read_slot->last_seq = frame_seq;
+	if (record_slot != nullptr) {                // behind the frame, on its stream: the order for the next frame under this policy key
+		VR_TRY(c, launch_tile_order(record_slot->cost, record_slot->order, ntiles, stream));
+		VR_TRY(c, hipEventRecord(record_slot->ready, stream));
+		record_slot->valid = true; record_slot->ntiles = ntiles; record_slot->stream = stream; record_slot->issue_seq = record_slot->last_seq = frame_seq;
+		oe->repeats++;
 	}
 	return VR_OK;
 }
@@ -812,6 +882,7 @@ void vr_hip_destroy(vr_ctx *c) {
 	if (c->bc_fault) (void) hipFree(c->bc_fault);
 #endif
 	for (auto &e : c->map_cache) { if (e.cost) (void) hipFree(e.cost); if (e.order) (void) hipFree(e.order); if (e.order_ready) (void) hipEventDestroy(e.order_ready); }
+	for (auto &e : c->order_cache) for (auto &sl : e.slot) { if (sl.cost) (void) hipFree(sl.cost); if (sl.order) (void) hipFree(sl.order); if (sl.ready) (void) hipEventDestroy(sl.ready); }
 	if (c->fb) (void) hipFree(c->fb);
 	if (c->tf) (void) hipFree(c->tf);
 	if (c->esl) (void) hipFree(c->esl);
@@ -928,7 +999,8 @@ int vr_hip_set_tile_scheduling(vr_ctx *c, uint32_t mode) {
 	if (c == nullptr) return VR_ERR_INVALID;
 	if (mode > 2u) return fail(c, VR_ERR_INVALID, "tile scheduling mode must be 0 (workgroup id), 1 (measured-cost order) or 2 (workgroup id + cost map)");
 	c->tile_scheduling = mode;
-	for (auto &e : c->map_cache) { e.order_state = 0; e.dual_state = 0; e.order_tiles = 0; }
+	for (auto &e : c->map_cache) { e.dual_state = 0; e.order_tiles = 0; }
+	for (auto &e : c->order_cache) { e.has_last = false; e.repeats = 0; for (auto &sl : e.slot) sl.valid = false; }      // (buffers and last-use marks stay: recycled only when free)
 	return VR_OK;
 }
 

@@ -153,6 +153,7 @@ __device__ __forceinline__ uint32_t fetch_voxel(const void *vol, const RayKernel
 		const uint32_t exy = lut[(int) L::x_at + kLutPad + ix] + lut[(int) L::y_at + kLutPad + iy];
 		const uint8_t *q;
 		constexpr uint32_t kBytes = LAYOUT == kLayoutVoxel ? BPV : 4u;       // what the load below reads
+		(void) kBytes;
 		if (ADDR == kAddr32) {
 			if (MANAGED && Managed<BPV, ADDR, LAYOUT>::value) {
 				uint32_t word;
@@ -254,6 +255,7 @@ __device__ __forceinline__ TriFetch<BPV, LAYOUT> tri_issue(const void *vol, cons
 	int ix = (int) xb, iy = (int) yb, iz = (int) zb;                // table layouts: -kLutPad .. dim - 1 + kLutPad are valid
 	if (LAYOUT != kLayoutLinear && ADDR != kAddrWide) {             // (debug build: each index against the table it is about to address)
 		const bool run_y = LAYOUT == kLayoutRunY;
+		(void) run_y;
 		ix = VR_BC_INDEX(a, 0, ix); iy = VR_BC_INDEX(a, run_y ? 2 : 1, iy); iz = VR_BC_INDEX(a, run_y ? 1 : 2, iz);
 	}
 	f.w0 = f.w1 = f.w2 = f.w3 = 0;
