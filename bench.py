@@ -474,7 +474,7 @@ def run_rank(a):
             if world == 1:
                 info = r.volume_info()
                 out["set_volume"] = {"upload_or_generate_ms": round(info.upload_ms, 3),
-                                     "copy_build_ms": {vr.COPY_NAMES[k]: round(info.build_ms[k], 3) for k in range(7) if (info.copies >> k) & 1},
+                                     "copy_build_ms": {vr.COPY_NAMES[k]: round(info.build_ms[k], 3) for k in range(vr.COPY_KINDS) if (info.copies >> k) & 1},
                                      "hbm_bytes": int(info.linear_bytes + info.bricked_bytes),
                                      "note": "brick copies are built by the first frame that reads them (vr_hip_prepare builds them ahead of time): "
                                              "what is listed is what this run's views and modes asked for so far"}

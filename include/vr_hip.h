@@ -152,7 +152,9 @@ int vr_hip_set_wide_addressing(vr_ctx *ctx, uint32_t force);
  * selection does for full-march frames of views that are not along a volume axis: which copy is cheaper depends on the cube face
  * a tile's rays enter through, so frames 0 - 3 of a parameter set run on one copy each (twice, the second time recording what every
  * tile cost) and from frame 4 on every tile reads the copy that was cheaper for it — here for every view; 7 = both copies on
- * alternating tiles (no measurement; parity tests).  Speed only; testing and tuning aid.  No reference counterpart. */
+ * alternating tiles (no measurement; parity tests); 8 = the column windows (VR_COPY_COL_*) along the view's major axis for EVERY orthogonal
+ * full-march frame — per-view selection reads them only when the view runs along a volume axis; 9 = never (the round-3 choice for
+ * those views).  Speed only; testing and tuning aid.  No reference counterpart. */
 int vr_hip_set_brick_plane(vr_ctx *ctx, int32_t plane);
 
 /* Which pixels of a 4x4-pixel block share a lane quad, and where the tile grid starts: speed only, images are identical.
@@ -189,7 +191,8 @@ int vr_hip_render_device(vr_ctx *ctx, const vr_params *params, void *dev_rgba, v
 /* What the last vr_hip_render* call of this context launched (tuning aid and test hook; no reference counterpart): the volume copy,
  * the lane order / wave shape / tile phase that were chosen (or forced), and the kernel's tile grid. */
 typedef struct vr_launch_info {
-	uint32_t layout;        /* 0 linear array, 1 quad bricks, 2 / 3 run bricks along z / y, 4 voxel bricks, 5 oct bricks, 6 both run copies (per tile) */
+	uint32_t layout;        /* 0 linear array, 1 quad bricks, 2 / 3 run bricks along z / y, 4 voxel bricks, 5 oct bricks, 6 both run copies (per tile),
+	                           7 column windows (brick_plane then holds the march axis 0 x, 1 y, 2 z) */
 	uint32_t brick_plane;   /* chunk plane of a quad copy: 0 (x,y), 1 (x,z), 2 (y,z) */
 	uint32_t lane_map;      /* (lane order) + 4 * (wave shape), as in vr_hip_set_tile_mapping */
 	uint32_t phase_x, phase_y;
@@ -277,8 +280,11 @@ uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
 #define VR_COPY_VOXEL    (1u << 5)   /* voxel bricks: NEAREST */
 #define VR_COPY_OCT      (1u << 6)   /* oct bricks (2-byte voxels only): one 16-byte element per cell = the whole 2x2x2 neighbourhood; what
                                         TRILINEAR reads for 2-byte voxels — one gather per sample instead of the quad bricks' two */
-#define VR_COPY_ALL      0x7fu
-#define VR_COPY_KINDS    7
+#define VR_COPY_COL_X    (1u << 7)   /* column windows along x / y / z (1-byte voxels, edges <= 2048): per cell column, four consecutive quad */
+#define VR_COPY_COL_Y    (1u << 8)   /* elements along the axis in ONE aligned 16-byte word; what TRILINEAR reads for full-march frames of */
+#define VR_COPY_COL_Z    (1u << 9)   /* ORTHOGONAL views along that axis: one gather and one transparency test per ~3 samples (vr_device.h) */
+#define VR_COPY_ALL      0x3ffu
+#define VR_COPY_KINDS    10
 int vr_hip_prepare(vr_ctx *ctx, uint32_t copies);
 /* Testing aid: the raw bytes of one resident brick copy (kind = bit index of its VR_COPY_* flag), so that a test can hold every copy
  * builder against a host-side construction of the layout, byte for byte.  *bytes_out (optional) = size of the copy; host_out may be

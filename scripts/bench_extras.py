@@ -138,7 +138,7 @@ def run_config(vr, name, device_index=0, layout=None, modes=("nooptims", "defaul
                 out[mode] = e
         info = r.volume_info()
         out["hbm_bytes"] = int(info.linear_bytes + info.bricked_bytes)
-        out["copies_built"] = [vr.COPY_NAMES[k] for k in range(7) if (info.copies >> k) & 1]
+        out["copies_built"] = [vr.COPY_NAMES[k] for k in range(vr.COPY_KINDS) if (info.copies >> k) & 1]
         out["setup_s"] = round(time.perf_counter() - t0, 2)
         return out
     finally:

@@ -2,10 +2,10 @@
 # round 4, call d: the whole -m gpu tier (incl. C5 whole frames, race test, bounds build), smoke, then bench.py with every extra leg
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04_d; mkdir -p $O
-timeout -k 10 1500 python -m pytest tests -m gpu -x -v 2>&1 | tee $O/tests.log | grep -E "PASSED|FAILED|ERROR|passed|failed|rror" | tail -70
+timeout -k 10 600 python -m pytest tests -m gpu -x -v 2>&1 | tee $O/tests.log | grep -E "PASSED|FAILED|ERROR|passed|failed|rror" | tail -70
 grep -q "failed" $O/tests.log && exit 1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout -k 10 1200 python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/r04_d/bench.json'))

@@ -32,9 +32,9 @@ def test_struct_layout_matches_header(vr):
     assert C.sizeof(vr.VrTiming) == 32 and vr.VrTiming.kernel_ms_max.offset == 24
     from importlib import import_module
     info = import_module("volume-rendering_amd.binding").VrVolumeInfo
-    # 10 u32 + 2 u64 + 3 u32 + 7 floats + 1 float = 40 + 16 + 12 + 32 = 100 bytes -> 104 (u64 fields 8-aligned at 40)
-    assert info.linear_bytes.offset == 40 and info.copies.offset == 56 and info.build_ms.offset == 68 and info.upload_ms.offset == 96
-    assert C.sizeof(info) == 104
+    # 10 u32 + 2 u64 + 3 u32 + VR_COPY_KINDS = 10 floats + 1 float = 40 + 16 + 12 + 44 = 112 bytes (u64 fields 8-aligned at 40)
+    assert info.linear_bytes.offset == 40 and info.copies.offset == 56 and info.build_ms.offset == 68 and info.upload_ms.offset == 108
+    assert C.sizeof(info) == 112
 
 
 def test_no_cpu_fallback(vr):

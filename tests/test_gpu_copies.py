@@ -99,23 +99,43 @@ def run_copy(vox, along_y):
     return out.reshape(-1)
 
 
+def column_copy(vox, m):
+    """column windows along axis m (vr_device.h kLayoutColumn): [block row bv][block bu][window w][column (v & 3, u & 3)] -> four quad elements
+    along m (march index 3w .. 3w+3, clamped at Nm - 1), each the 2x2 (u,v) neighbourhood with the +1 neighbours clamped at the upper faces;
+    (u, v) = the two other axes in increasing order.  Columns beyond the volume hold the clamped edge columns."""
+    dims = vox.shape[::-1]                                   # (x, y, z)
+    ua, va = (1 if m == 0 else 0), (1 if m == 2 else 2)
+    nu, nv, nm = dims[ua], dims[va], dims[m]
+    nbu, nbv, nw = (nu + 3) // 4, (nv + 3) // 4, (nm + 2) // 3
+    bv, bu, w, cv, cu, j = np.meshgrid(np.arange(nbv), np.arange(nbu), np.arange(nw), np.arange(4), np.arange(4), np.arange(4), indexing="ij")
+    u, v, e = bu * 4 + cu, bv * 4 + cv, np.minimum(w * 3 + j, nm - 1)
+    out = np.zeros(u.shape + (4,), np.uint8)
+    for i, (du, dv) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
+        idx = [None, None, None]
+        idx[ua], idx[va], idx[m] = np.minimum(u + du, nu - 1), np.minimum(v + dv, nv - 1), e
+        out[..., i] = vox[idx[2], idx[1], idx[0]]
+    return out.reshape(-1)
+
+
 def _volume(shape, dtype, seed):
     rng = np.random.default_rng(seed)
     hi = 256 if dtype == np.uint8 else 65536
     return rng.integers(0, hi, size=shape, dtype=dtype)
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 64), (40, 24, 56), (9, 130, 17), (8, 8, 264)])      # (z, y, x)
+@pytest.mark.parametrize("shape", [(64, 64, 64), (40, 24, 56), (9, 130, 17), (8, 8, 264), (3, 301, 2)])      # (z, y, x)
 def test_u8_copies_equal_the_host_construction(vr, gpu, shape):
     vox = _volume(shape, np.uint8, 7)
     gpu.set_layout(vr.LAYOUT_BRICKED)
     gpu.set_volume(vox)
-    gpu.prepare(vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_QUAD_YZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y | vr.COPY_VOXEL)
+    gpu.prepare(vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_QUAD_YZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y | vr.COPY_VOXEL | vr.COPY_COL_X | vr.COPY_COL_Y | vr.COPY_COL_Z)
     for plane in range(3):
         assert np.array_equal(gpu.download_copy(plane), quad_copy(vox, plane)), ("quad", plane)
     assert np.array_equal(gpu.download_copy(3), run_copy(vox, False)), "run z"
     assert np.array_equal(gpu.download_copy(4), run_copy(vox, True)), "run y"
     assert np.array_equal(gpu.download_copy(5), voxel_copy(vox)), "voxel"
+    for m in range(3):
+        assert np.array_equal(gpu.download_copy(7 + m), column_copy(vox, m)), ("column windows along", "xyz"[m])
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 32), (17, 40, 137)])

@@ -173,6 +173,66 @@ def test_trilinear_layouts_agree(vr, gpu, golden, oracle):
             gpu.set_brick_plane(-1)
 
 
+def test_column_march_matches_oracle(vr, gpu, golden, oracle):
+    """kLayoutColumn (colmarch_kernel): full-march TRILINEAR frames of orthogonal views along a volume axis read the column windows and march
+    on wave-uniform state; poses whose direction carries rounding noise make lanes flip cell columns mid-march (careful windows), windows
+    that do not hold three cells end the volume (edges 32, 40, 24, 56), tile phases shift the waves over the columns.  Forced
+    (vr_hip_set_brick_plane(8)) every orthogonal full-march frame takes the kernel, oblique ones mostly through its per-lane march."""
+    poses = ((0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (180.0, 90.0, 0.0), (0.0, 90.0, 0.0), (270.0, 0.0, 0.0), (0.0, 180.0, 0.0), (90.0, 90.0, 0.0), (0.0, 0.0, 90.0))
+    for name, label, sizes in (("bucky", "bench64_view1_default", ((256, 256), (130, 67))), ("blob_40x24x56", "view1_default", ((192, 160),))):
+        st = load_volume(gpu, golden, name)
+        case = [c for c in golden.cases(True) if c["label"] == label and c["volume"] == name][0]
+        for (w, h) in sizes:
+            gpu.set_window_buffer(w, h)
+            for angles in poses + ((0.02, 0.0, 0.0), (90.0, 0.013, 0.0), (-45.0, -45.0, 0.0), (1.5, 2.5, 0.0)):
+                axis_aligned = angles in poses
+                for samp, kd, step_scale in ((vr.SAMPLE_TRILINEAR, 0.6, 1.0), (vr.SAMPLE_TRILINEAR_Q8, 0.0, 1.0), (vr.SAMPLE_TRILINEAR, 0.6, 0.37)):
+                    p = golden.params(case, samp)
+                    v = vr.custom_view(w, h, False, angles, 2.0)
+                    for f in ("origin", "direction", "right_plane", "up_plane"):
+                        for j in range(3):
+                            getattr(p.view, f)[j] = getattr(v, f)[j]
+                    p.view.width, p.view.height, p.view.perspective = w, h, 0
+                    p = vr.whole_frame(p)
+                    p.esl, p.ray_threshold, p.light_kd = 0, 1.0, kd
+                    p.ray_step = float(np.float32(p.ray_step) * np.float32(step_scale))
+                    want = oracle.render(p, golden.voxels(name), st["tf"], st["esl"])
+                    gpu.set_brick_plane(-1)
+                    assert np.array_equal(gpu.render_volume(p), want), (name, angles, samp, kd, step_scale, "automatic")
+                    if axis_aligned:
+                        assert gpu.last_launch()["layout"] == 7, (name, angles, gpu.last_launch())
+                    gpu.set_brick_plane(8)
+                    assert np.array_equal(gpu.render_volume(p), want), (name, angles, samp, kd, step_scale, "forced")
+                    assert gpu.last_launch()["layout"] == 7, (name, angles, gpu.last_launch())
+                    gpu.set_brick_plane(9)
+                    assert np.array_equal(gpu.render_volume(p), want), (name, angles, samp, kd, step_scale, "never")
+                    assert gpu.last_launch()["layout"] != 7
+            # a band partition and forced tile phases move the waves over the cell columns
+            p = golden.params(case, vr.SAMPLE_TRILINEAR)
+            v = vr.custom_view(w, h, False, (180.0, 90.0, 0.0), 2.0)
+            for f in ("origin", "direction", "right_plane", "up_plane"):
+                for j in range(3):
+                    getattr(p.view, f)[j] = getattr(v, f)[j]
+            p.view.width, p.view.height, p.view.perspective = w, h, 0
+            p = vr.whole_frame(p)
+            p.esl, p.ray_threshold = 0, 1.0
+            want = oracle.render(p, golden.voxels(name), st["tf"], st["esl"])
+            gpu.set_brick_plane(-1)
+            for lane_map in (0, 1, 2):
+                for ph in ((0, 0), (3, 5), (7, 1)):
+                    gpu.set_tile_mapping(lane_map, *ph)
+                    assert np.array_equal(gpu.render_volume(p), want), (name, lane_map, ph)
+                    assert gpu.last_launch()["layout"] == 7
+            gpu.set_tile_mapping(-1)
+            rows = []
+            for rank in range(3):
+                pb, _ = vr.band_partition(p.copy(), rank, 3, 16)
+                rows.append((pb, gpu.render_volume(pb)))
+            for rank, (pb, img) in enumerate(rows):
+                assert np.array_equal(img, oracle.render(pb, golden.voxels(name), st["tf"], st["esl"])), (name, "band", rank)
+    gpu.set_brick_plane(-1)
+
+
 def test_u16_volume_matches_oracle(vr, gpu, golden, oracle):
     """Build-side extension (the reference quantises 16-bit data to 8 bit on load, ModelBase.cpp:95-98)."""
     vox16 = golden.voxels("bucky").astype(np.uint16) * 257
@@ -536,8 +596,9 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         r.prepare()                                                            # everything the policy has
         info = r.volume_info()
         assert info.copies == vr.COPY_ALL & ~vr.COPY_OCT and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7 and info.run_copy == 7
-        assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3
-        assert all(ms > 0 for ms in list(info.build_ms)[:6]) and info.build_ms[6] == 0 and info.copies_refused == 0 and info.upload_ms > 0
+        assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3 + 3 * (8 * 8 * 11 * 256)       # + three column-window copies
+        assert all(ms > 0 for ms in list(info.build_ms)[:6]) and info.build_ms[6] == 0 and all(ms > 0 for ms in list(info.build_ms)[7:10])
+        assert info.copies_refused == 0 and info.upload_ms > 0
         before = [near, tri]
         r.release_linear_copy()
         info = r.volume_info()

@@ -69,6 +69,7 @@ struct RayKernelArgs {
 	uint32_t dual_analytic;            // kLayoutRunDual: 1 = every tile picks its run copy from dual_bits (no launch-order entry needed)
 	uint32_t dual_shift;               // ... one bit per group of (1 << dual_shift) consecutive tile NUMBERS (>= 6: 64 numbers = one 8x8-tile block of the numbering)
 	uint32_t dual_bits[32];            // ... bit set = the block's tiles read the copy with runs along y (vr_hip_api.cpp dual_choice_bits)
+	uint32_t col_axis;                 // kLayoutColumn: the march axis m (0 x, 1 y, 2 z) of the window copy handed to the kernel
 #ifdef VR_BOUNDS_CHECK
 	// `make EXTRA=-DVR_BOUNDS_CHECK` (debug build, not the product): every gather address of the march is held against the array it must
 	// lie in, every address-table index against its padded table, the tile-cost slot against its buffer; the first violation is recorded
@@ -144,7 +145,16 @@ struct TileSchedule { const uint32_t *order = nullptr; uint32_t *cost = nullptr;
 //                   plane parallel to it — with runs perpendicular to that plane no two lanes share a run (measured per tile on the
 //                   oblique benchmark pose: the upper half of the screen is 25 % cheaper with runs along y, the lower half with runs
 //                   along z).  The host measures both copies per tile on the first two frames of a parameter set (vr_hip_api.cpp).
-enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5, kLayoutRunDual = 6 };
+//   kLayoutColumn : "column windows" (round 4) for ORTHOGONAL views along a volume axis m, full march.  Every ray of such a view stays in
+//                   one cell column (u,v) for its whole march (but for at most one cell flip per lateral axis when the direction carries
+//                   rounding noise), and all rays share one k sequence, so the cell ALONG the march is the same for the whole wave at
+//                   every sample.  The copy holds, per cell column, WINDOWS of four consecutive quad elements along m (element e =
+//                   the 2x2 (u,v) neighbourhood at march index min(e, Nm-1); window w = elements 3w .. 3w+3 = the three cells
+//                   3w .. 3w+2) as ONE aligned 16-byte word; the 4x4 columns of a lateral block are contiguous (256 bytes) and a
+//                   block's windows follow each other along m: address = ((bv * nbu + bu) * nw + w) * 256 + (v & 3) * 64 + (u & 3) * 16.
+//                   One 16-byte gather serves the ~3 samples of a window, its transparency test is done once for the window, and the
+//                   address chain of a sample shrinks to the wave-uniform cell along m (colmarch_kernel).  16/3 bytes per voxel.
+enum : uint32_t { kLayoutLinear = 0, kLayoutBricked = 1, kLayoutRun = 2, kLayoutRunY = 3, kLayoutVoxel = 4, kLayoutOct = 5, kLayoutRunDual = 6, kLayoutColumn = 7 };
 __host__ __device__ constexpr bool is_run_layout(int layout) { return layout == (int) kLayoutRun || layout == (int) kLayoutRunY || layout == (int) kLayoutRunDual; }
 constexpr uint32_t kDualWords = 32;
 constexpr uint32_t kTileAltBit = 0x80000000u;       // kLayoutRunDual: set in a launch-order entry = this tile reads the copy with runs along y
@@ -171,7 +181,22 @@ constexpr uint32_t kBrickEdge = 8, kBrickPitch = 512;
 enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
 // the brick copies a context may hold (bit i of vr_hip_prepare's mask / vr_volume_info::copies = copy i): quad bricks per chunk
 // plane, run bricks along z / y, voxel bricks
-enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyOct = 6, kCopyKinds = 7 };
+enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyOct = 6,
+                  kCopyColX = 7, kCopyColY = 8, kCopyColZ = 9,        // column windows along x / y / z (kLayoutColumn)
+                  kCopyKinds = 10 };
+static_assert(kCopyKinds == VR_COPY_KINDS, "include/vr_hip.h VR_COPY_KINDS");
+// column windows (kLayoutColumn): lateral axes (u, v) of march axis m are the two other axes in increasing order
+constexpr uint32_t kColCells = 3, kColWindowBytes = 16, kColBlockBytes = 256;       // cells per window; 4x4 columns x 16 bytes
+__host__ __device__ constexpr uint32_t col_axis_u(uint32_t m) { return m == 0u ? 1u : 0u; }
+__host__ __device__ constexpr uint32_t col_axis_v(uint32_t m) { return m == 2u ? 1u : 2u; }
+__host__ __device__ inline uint32_t col_windows(uint32_t nm) { return (nm + kColCells - 1u) / kColCells; }
+// The march prefetches windows past a ray's exit and addresses them by a running pointer without clamping the window index: inside
+// the copy that reads a neighbouring block's windows (never used: those samples lie outside every segment), at its two ends it reads
+// this much zeroed padding (64 windows).  The kernel bounds its window count by the windows left in march direction + kColSlots + 2 (colmarch_kernel).
+constexpr uint32_t kColPadBytes = 64u * kColBlockBytes;
+inline uint64_t col_copy_bytes(const uint32_t dim[3], uint32_t m) {      // without the padding
+	return (uint64_t) ((dim[col_axis_u(m)] + 3u) / 4u) * ((dim[col_axis_v(m)] + 3u) / 4u) * col_windows(dim[m]) * kColBlockBytes;
+}
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
 	constexpr uint8_t table[4][9] = {
@@ -206,6 +231,8 @@ hipError_t launch_brickify_oct(const void *linear, void *oct_bricks, uint32_t di
 // linear -> run bricks (1-byte voxels)
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout /* kLayoutRun | kLayoutRunY */, uint32_t dim_x, uint32_t dim_y,
                                uint32_t dim_z, hipStream_t stream);
+// linear -> column windows along axis m (1-byte voxels)
+hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 // number of quad elements (each 4 * bytes_per_voxel bytes)
 inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 	return (uint64_t) ((dim_x + kBrickEdge - 1) / kBrickEdge) * ((dim_y + kBrickEdge - 1) / kBrickEdge) *

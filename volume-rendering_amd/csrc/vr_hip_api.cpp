@@ -48,9 +48,10 @@ struct vr_ctx {
 	// builds the (x,z) / (y,z) planes.  copy[kCopyQuadXY..YZ] = quad bricks per chunk plane, kCopyRunZ / kCopyRunY = run bricks,
 	// kCopyVoxel = voxel bricks (what NEAREST reads), kCopyOct = oct bricks (what TRILINEAR reads for 2-byte voxels).  copy_failed: a build was refused (HBM guard / allocation) — not retried
 	// until the next set_volume, so a frame never stalls twice on the same refusal.
-	void *copy[kCopyKinds] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-	float copy_build_ms[kCopyKinds] = { 0, 0, 0, 0, 0, 0, 0 };
-	bool copy_failed[kCopyKinds] = { false, false, false, false, false, false, false };
+	void *copy[kCopyKinds] = {};            // kCopyColX..Z = column windows along x / y / z (orthogonal full-march frames along that axis)
+	float copy_build_ms[kCopyKinds] = {};
+	bool copy_failed[kCopyKinds] = {};
+	int32_t column_force = 0;               // vr_hip_set_brick_plane: 0 = per view (views along a volume axis), 1 (plane 8) = every orthogonal full-march frame, -1 (plane 9) = never
 	float upload_ms = 0;                    // host -> HBM copy (or generation) of the linear array in the last set_volume
 	int32_t brick_plane_force = -1;         // -1 = per view (plane perpendicular to the dominant view axis; run bricks for oblique views),
 	                                        // 0..2 = that chunk plane, 3 = the run bricks (testing)
@@ -510,6 +511,28 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			a.layout = kLayoutRunDual;
 		}
 	}
+	// Column windows (kLayoutColumn, vr_device.h): full-march TRILINEAR frames of ORTHOGONAL views along a volume axis — every ray stays in
+	// one cell column (at most one cell flip per lateral axis: the direction's other components are rounding noise), all rays share the k
+	// sequence, and colmarch_kernel marches on wave-uniform state: one 16-byte gather and one transparency test per ~3 samples.  What the
+	// host checks: the lateral drift over the longest possible segment stays below half a cell, a sample advances between 1/64 and 1 cell
+	// along the axis (the kernel re-checks both per wave and otherwise marches per lane), at most one cell per pixel (the 32-bit offsets
+	// of a wave's columns), no clamping instantiation.  Measured on the benchmark poses (full march, lit): 2.12 / 2.13 / 2.86 ms before.
+	if (p->sampling != VR_SAMPLE_NEAREST && bricked && c->bpv == 1 && !c->force_wide && !p->view.perspective && !p->esl && p->ray_threshold >= 1.0f &&
+	    !a.clamp_fetch && c->column_force >= 0 && (c->brick_plane_force < 0 || c->column_force > 0)) {
+		const float half[3] = { a.half_x, a.half_y, a.half_z };
+		float d[3];
+		for (int i = 0; i < 3; i++) d[i] = std::fabs(p->view.direction[i] * half[i]);
+		const int m = d[2] >= d[0] && d[2] >= d[1] ? 2 : (d[1] >= d[0] ? 1 : 0);
+		const float advance = d[m] * p->ray_step;
+		bool take = advance >= 1.0f / 64.0f && advance <= 1.0f;
+		for (int i = 0; i < 3; i++) if ((std::fabs(p->view.right_plane[i]) + std::fabs(p->view.up_plane[i])) * half[i] > 1.0f) take = false;
+		if (c->column_force == 0)                                          // per view: along the axis — 4 > 2 sqrt(3), the longest segment in k
+			for (int i = 0; i < 3; i++) if (i != m && d[i] * 4.0f >= 0.45f) take = false;
+		if (take && copy_possible(c, kCopyColX + (uint32_t) m)) {
+			a.layout = kLayoutColumn; a.col_axis = (uint32_t) m; a.brick_plane = (uint32_t) m;
+			dual_analytic = false; dual_stage = -1;
+		}
+	}
 	// The copy this frame reads, built now if this is its first use.  A build that is refused (HBM guard, allocation, linear array
 	// released) degrades to the next best resident copy; the image is the same.
 	const void *brick_copy = nullptr;
@@ -520,7 +543,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 	if (a.layout != kLayoutLinear && brick_copy == nullptr) {
 		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
-		                      a.layout == kLayoutOct ? kCopyOct : kCopyQuadXY + a.brick_plane;
+		                      a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? kCopyColX + a.col_axis : kCopyQuadXY + a.brick_plane;
 		brick_copy = copy_for(c, want);
 		if (brick_copy == nullptr && want != kCopyQuadXY) {
 			a.layout = kLayoutBricked; a.brick_plane = kPlaneXY;
@@ -685,10 +708,11 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	{   // debug build: what the frame's gathers must stay inside, and where the first violation is recorded
 		if (c->bc_fault == nullptr) { VR_TRY(c, hipMalloc((void **) &c->bc_fault, 8 * sizeof(uint32_t))); VR_TRY(c, hipMemset(c->bc_fault, 0, 8 * sizeof(uint32_t))); }
 		const void *array = plan.reads_linear ? c->vol : brick_copy;
-		a.bc_base = (uint64_t) (uintptr_t) array;
+		a.bc_base = (uint64_t) (uintptr_t) array - (a.layout == kLayoutColumn ? kColPadBytes : 0u);
 		a.bc_bytes = plan.reads_linear ? (c->vol_elems + volume_tail_slack(c->dim[0], c->dim[1])) * c->bpv :
 		             copy_bytes(c, a.layout == kLayoutRun || a.layout == kLayoutRunDual ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
-		                           a.layout == kLayoutOct ? kCopyOct : kCopyQuadXY + a.brick_plane);
+		                           a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? kCopyColX + a.col_axis : kCopyQuadXY + a.brick_plane);
+		if (a.layout == kLayoutColumn) a.bc_bytes += 2ull * kColPadBytes;
 		a.bc_alt_bytes = a.alt_copy ? copy_bytes(c, kCopyRunY) : 0;
 		a.bc_fault = c->bc_fault; a.bc_ntiles = ntiles;
 		// self-test of the net itself: VR_BC_SELFTEST=1 halves the size the checks hold the gathers against — a full-march frame must then fail
@@ -752,7 +776,7 @@ hipError_t drain(vr_ctx *c) {
 
 void free_bricks(vr_ctx *c) {
 	for (uint32_t k = 0; k < kCopyKinds; k++) {
-		if (c->copy[k]) { (void) hipFree(c->copy[k]); c->copy[k] = nullptr; }
+		if (c->copy[k]) { (void) hipFree(k >= kCopyColX && k <= kCopyColZ ? (uint8_t *) c->copy[k] - kColPadBytes : (uint8_t *) c->copy[k]); c->copy[k] = nullptr; }
 		c->copy_build_ms[k] = 0; c->copy_failed[k] = false;
 	}
 }
@@ -763,6 +787,7 @@ uint64_t copy_bytes(const vr_ctx *c, uint32_t kind) {
 	if (kind <= kCopyQuadYZ) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 4 * c->bpv;
 	if (kind == kCopyVoxel) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
 	if (kind == kCopyOct) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 8 * c->bpv;
+	if (kind >= kCopyColX && kind <= kCopyColZ) return col_copy_bytes(c->dim, kind - kCopyColX);
 	return run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
 }
 
@@ -773,6 +798,7 @@ bool copy_in_policy(const vr_ctx *c, uint32_t kind) {
 	if (kind == kCopyQuadXY) return true;
 	if (kind == kCopyVoxel) return max_dim_of(c) <= 2048u;
 	if (kind == kCopyOct) return c->bpv == 2 && max_dim_of(c) <= 2048u;
+	if (kind >= kCopyColX && kind <= kCopyColZ) return c->bpv == 1 && max_dim_of(c) <= 2048u;
 	if (kind == kCopyQuadXZ || kind == kCopyQuadYZ) return c->bpv == 1 && max_dim_of(c) <= 1024u && copy_bytes(c, kind) <= (1ull << 32);
 	return c->bpv == 1 && max_dim_of(c) <= 1024u;
 }
@@ -796,17 +822,25 @@ int build_copy(vr_ctx *c, uint32_t kind) {
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) { (void) hipGetLastError(); c->copy_failed[kind] = true; return VR_ERR_ALLOC; }
 	}
 	void *dst = nullptr;
-	if (hipMalloc(&dst, bytes) != hipSuccess) { (void) hipGetLastError(); c->copy_failed[kind] = true; return fail(c, VR_ERR_ALLOC, "brick copy allocation failed"); }
-	hipError_t e = hipEventRecord(c->aux_start, c->stream);
+	const bool column = kind >= kCopyColX && kind <= kCopyColZ;          // column windows: zeroed padding in front and behind (vr_device.h kColPadBytes)
+	if (hipMalloc(&dst, bytes + (column ? 2ull * kColPadBytes : 0ull)) != hipSuccess) { (void) hipGetLastError(); c->copy_failed[kind] = true; return fail(c, VR_ERR_ALLOC, "brick copy allocation failed"); }
+	hipError_t e = hipSuccess;
+	if (column) {
+		e = hipMemsetAsync(dst, 0, kColPadBytes, c->stream);
+		if (e == hipSuccess) e = hipMemsetAsync((uint8_t *) dst + kColPadBytes + bytes, 0, kColPadBytes, c->stream);
+		dst = (uint8_t *) dst + kColPadBytes;                            // what kernels and downloads see; free_bricks undoes the offset
+	}
+	if (e == hipSuccess) e = hipEventRecord(c->aux_start, c->stream);
 	if (e == hipSuccess) {
 		if (kind <= kCopyQuadYZ) e = launch_brickify(c->vol, dst, c->bpv, kind - kCopyQuadXY, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else if (kind == kCopyVoxel) e = launch_brickify_voxel(c->vol, dst, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else if (kind == kCopyOct) e = launch_brickify_oct(c->vol, dst, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else if (kind >= kCopyColX && kind <= kCopyColZ) e = launch_build_column(c->vol, dst, kind - kCopyColX, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else e = launch_brickify_run(c->vol, dst, kind == kCopyRunY ? kLayoutRunY : kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream);
 	}
 	if (e == hipSuccess) e = hipEventRecord(c->aux_stop, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	if (e != hipSuccess) { (void) hipGetLastError(); (void) hipFree(dst); c->copy_failed[kind] = true; return fail(c, VR_ERR_HIP, "brick copy build failed", e); }
+	if (e != hipSuccess) { (void) hipGetLastError(); (void) hipFree(column ? (uint8_t *) dst - kColPadBytes : (uint8_t *) dst); c->copy_failed[kind] = true; return fail(c, VR_ERR_HIP, "brick copy build failed", e); }
 	(void) hipEventElapsedTime(&c->copy_build_ms[kind], c->aux_start, c->aux_stop);
 	c->copy[kind] = dst;
 	return VR_OK;
@@ -986,9 +1020,17 @@ int vr_hip_set_wide_addressing(vr_ctx *c, uint32_t force) {
 
 int vr_hip_set_brick_plane(vr_ctx *c, int32_t plane) {
 	if (c == nullptr) return VR_ERR_INVALID;
+	if (plane == (int32_t) kPlanes + 5 || plane == (int32_t) kPlanes + 6) {      // 8 / 9: the column windows for every orthogonal full-march frame / never
+		c->column_force = plane == (int32_t) kPlanes + 5 ? 1 : -1;
+		c->oct_always = false; c->brick_plane_force = -1;
+		c->map_cached = 0; c->map_next = 0;
+		return VR_OK;
+	}
+	c->column_force = 0;
 	if (plane < -1 || plane > (int32_t) kPlanes + 4)
 		return fail(c, VR_ERR_INVALID, "plane must be -1 (per view), 0 (x,y), 1 (x,z), 2 (y,z), 3 (run bricks along z), 4 (run bricks along y), 5 (oct bricks for every view of a "
-		                               "2-byte volume), 6 (both run copies, chosen per tile by measurement, for every full-march view) or 7 (both run copies on alternating tiles)");
+		                               "2-byte volume), 6 (both run copies, chosen per tile by measurement, for every full-march view), 7 (both run copies on alternating tiles), "
+		                               "8 (column windows for every orthogonal full-march frame) or 9 (never the column windows)");
 	c->oct_always = plane == (int32_t) kPlanes + 2;
 	c->brick_plane_force = c->oct_always ? -1 : plane;
 	c->map_cached = 0; c->map_next = 0;          // cached lane orders were chosen for another plane

@@ -1044,6 +1044,372 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	}
 }
 
+// ---- the column march (kLayoutColumn, round 4) -----------------------------------------------------------------------------------
+//
+// Orthogonal views along a volume axis m, full march (no leaping, no early termination).  What makes them special (measured on the
+// benchmark poses, scripts: every 8x8-pixel tile of the three axis-aligned views): all rays of a wave share kx bit for bit, so they
+// share the whole k sequence, and with the direction's lateral components at most rounding noise (4e-8) a ray stays in ONE cell column
+// (u,v) but for at most one cell flip per lateral axis.  The march therefore runs on wave-uniform state:
+//   * the cell along m of a sample is the same for all 64 lanes: k += step, fma, float -> int, v_readfirstlane — four vector
+//     instructions per sample instead of the 15 + 3 LDS lookups of the general address chain;
+//   * ONE aligned 16-byte gather per lane and WINDOW (four consecutive quad elements of the lane's column = three cells, vr_device.h),
+//     prefetched kColDepth windows ahead with exact s_waitcnt vmcnt accounting (one gather per window: static);
+//   * the transparency test is done ONCE per window on all four elements: a window that is transparent for every live lane lets its
+//     ~3 samples pass with the uniform chain alone (exact: every pair of elements the samples would test is part of the window);
+//   * a lane whose column flips (monotone coordinate: at most once per axis, at the smallest float t with cell(t) != cell(kx), found by
+//     bisection once per ray) reads the column of the state PREDICTED for a window's first sample; a window whose samples may see a
+//     different state (t inside the window's k range, or between prediction and truth) takes the careful path: explicit per-sample
+//     fetches from each lane's true column.
+// Waves whose live lanes do not share kx and the coordinate along m (none on pose (0,0,0) and (90,0,0), 256 of 65536 on (180,90,0)),
+// whose columns would flip by more than one cell, or whose lateral spread leaves the 32-bit offset range, march per lane with explicit
+// fetches from the same copy (exact, unpipelined).  Arithmetic per composited sample is the general kernel's, expression by expression.
+#ifndef VR_COL_DEPTH
+#define VR_COL_DEPTH 3
+#endif
+constexpr int kColDepth = VR_COL_DEPTH, kColSlots = kColDepth + 1;
+
+__device__ __forceinline__ void managed_load128_s(u32x4 &dst, uint32_t byte_offset, uint64_t base) {     // window gather: scalar base + per-lane offset
+	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_offset), "s"(base));
+}
+template <int I> __device__ __forceinline__ float comp3(const f3 &v) { return I == 0 ? v.x : (I == 1 ? v.y : v.z); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ float rlane(float v, int lane) { return __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), lane)); }
+
+// the eight corner voxels of a sample out of the two quad elements along m (w0 = march index i, w1 = i + 1) -> trilinear value;
+// element bytes are (u,v), (u+1,v), (u,v+1), (u+1,v+1) with (u,v) the lateral axes of m in increasing order; lerps in x, y, z order
+template <int M, bool Q8>
+__device__ __forceinline__ float col_resolve(uint32_t w0, uint32_t w1, const RayKernelArgs &a, float xb, float yb, float zb) {
+	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x)));
+	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y)));
+	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z)));
+	const float p0 = (float) (w0 & 0xffu), p1 = (float) ((w0 >> 8) & 0xffu), p2 = (float) ((w0 >> 16) & 0xffu), p3 = (float) (w0 >> 24);
+	const float q0 = (float) (w1 & 0xffu), q1 = (float) ((w1 >> 8) & 0xffu), q2 = (float) ((w1 >> 16) & 0xffu), q3 = (float) (w1 >> 24);
+	float v000, v100, v010, v110, v001, v101, v011, v111;
+	if (M == 2)      { v000 = p0; v100 = p1; v010 = p2; v110 = p3; v001 = q0; v101 = q1; v011 = q2; v111 = q3; }      // (u,v) = (x,y), pair along z
+	else if (M == 1) { v000 = p0; v100 = p1; v001 = p2; v101 = p3; v010 = q0; v110 = q1; v011 = q2; v111 = q3; }      // (u,v) = (x,z), pair along y
+	else             { v000 = p0; v010 = p1; v001 = p2; v011 = p3; v100 = q0; v110 = q1; v101 = q2; v111 = q3; }      // (u,v) = (y,z), pair along x
+	const float c00 = lerp(v000, v100, ax), c10 = lerp(v010, v110, ax);
+	const float c01 = lerp(v001, v101, ax), c11 = lerp(v011, v111, ax);
+	const float c0 = lerp(c00, c10, ay), c1 = lerp(c01, c11, ay);
+	return lerp(c0, c1, az);
+}
+
+template <int SAMPLING, int M>
+#ifndef VR_COL_WAVES
+#define VR_COL_WAVES 8
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(VR_COL_WAVES, VR_COL_WAVES)))       // 64 VGPRs at 8 waves per SIMD (prefetch depth 3)
+void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, const float *__restrict__ tf_g, uint32_t *__restrict__ out) {
+	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;
+	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
+	__shared__ f4 tf_l[VR_TF_SIZE + 1], dtf_l[VR_TF_SIZE + 1];
+	{
+		const uint32_t t = threadIdx.x;
+		if (t <= VR_TF_SIZE) {
+			const f4 *tf4 = (const f4 *) tf_g;
+			const uint32_t i0 = t < VR_TF_SIZE ? t : VR_TF_SIZE - 1, i1 = t + 1 < VR_TF_SIZE ? t + 1 : VR_TF_SIZE - 1;
+			const f4 c0 = tf4[i0], c1 = tf4[i1];
+			tf_l[t] = c0;
+			f4 d; d.x = c1.x - c0.x; d.y = c1.y - c0.y; d.z = c1.z - c0.z; d.w = c1.w - c0.w;
+			dtf_l[t] = d;
+		}
+	}
+	__syncthreads();
+	uint32_t tile_x, tile_y;
+	tile_to_xy(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
+	// pixel of this lane: the general kernel's mapping (lane order, 8x8 waves, tile phase)
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, qd = lane >> 4;
+	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;
+	const uint32_t order = a.lane_map & 3u;
+	if (order == kLaneBlocks) { gu = ((lane >> 1) & 2u) | (lane & 1u); gv = ((lane >> 2) & 2u) | ((lane >> 1) & 1u); }
+	else if (order == kLaneColumns) { const uint32_t t = gu; gu = gv; gv = t; }
+	const uint32_t wx = (qd & 1u) * 4u + gu, wy = (qd >> 1) * 4u + gv, ox = (wave & 3u) * 8u, oy = (wave >> 2) * 8u;
+	const uint32_t lx = tile_x * 32u + ox + wx - a.phase_x, ly = tile_y * 16u + oy + wy - a.phase_y;
+	// lanes outside the buffer stay in the wave (the batched sample sequence below lives in all 64 lanes): no segment, no store
+	const bool in_frame = lx < a.p.out_width && ly < a.p.out_rows;
+	const uint32_t band = ly / a.p.band_rows;
+	const uint32_t gy = (band * a.p.band_stride + a.p.band_first) * a.p.band_rows + (ly - band * a.p.band_rows);
+	const uint32_t gx = a.p.x0 + lx;
+	const uint32_t out_index = ly * a.p.out_width + lx;                      // (frames are at most 65535 x 65535 pixels, validate_params; < 2^32 for in-frame lanes)
+
+	// -- View::get_ray (ViewBase.h:23-35), orthogonal branch only (the host never launches this kernel for a perspective view)
+	bool alive = in_frame && gx < a.p.view.width && gy < a.p.view.height;
+	const f3 dir = ld3(a.p.view.direction);
+	f3 origin;
+	{
+		const f3 vo = ld3(a.p.view.origin), vr_ = ld3(a.p.view.right_plane), vu = ld3(a.p.view.up_plane);
+		const float fx = (float) ((int) gx - (int) (a.p.view.width / 2u)), fy = (float) ((int) gy - (int) (a.p.view.height / 2u));
+		origin = mk3(vo.x + vr_.x * fx, vo.y + vr_.y * fx, vo.z + vr_.z * fx);
+		origin = mk3(origin.x + vu.x * fy, origin.y + vu.y * fy, origin.z + vu.z * fy);
+	}
+	float kx = 0, ky = 0;
+	alive = alive && intersect(origin, dir, kx, ky);
+	const float step = a.p.ray_step;
+	alive = alive && (ky + step > ky);                                       // termination guard (see raymarch_kernel)
+	ky = flmin(ky, kx + step * (float) kMaxRaySteps);
+	const bool hit = alive;
+	const uint64_t alive_mask = __builtin_amdgcn_ballot_w64(alive);
+	if (alive_mask == 0ull) { if (in_frame) out[out_index] = 0u; return; }
+
+	// texel-space ray (oracle/vr_oracle.c axis_setup): coordinate = fma(k, A, B); A is wave-uniform (orthogonal view)
+	// (the same value in every lane, formed by the vector unit: moved to scalar registers so that it does not occupy three VGPRs for the whole march)
+	auto uni = [](float v) { return __uint_as_float(rfl(__float_as_uint(v))); };
+	const f3 A = mk3(uni(dir.x * a.half_x), uni(dir.y * a.half_y), uni(dir.z * a.half_z));
+	const f3 B = mk3(VR_FMA(origin.x, a.half_x, a.off_x), VR_FMA(origin.y, a.half_y, a.off_y), VR_FMA(origin.z, a.half_z, a.off_z));
+	const float Am = comp3<M>(A), Au = comp3<U>(A), Av = comp3<V>(A);
+	const float Bm = comp3<M>(B), Bu = comp3<U>(B), Bv = comp3<V>(B);
+	const uint32_t dim_u = U == 0 ? a.dim_x : a.dim_y, dim_v = V == 1 ? a.dim_y : a.dim_z, dim_m = M == 0 ? a.dim_x : (M == 1 ? a.dim_y : a.dim_z);
+	const float max_u = U == 0 ? a.max_x : a.max_y, max_v = V == 1 ? a.max_y : a.max_z;
+	const uint32_t nbu = (dim_u + 3u) >> 2, nw = col_windows(dim_m);
+	const uint64_t stride_u = (uint64_t) nw * kColBlockBytes, stride_v = (uint64_t) nbu * stride_u;       // bytes between lateral blocks
+	auto f_u = [&](int c) { return (uint64_t) ((uint32_t) c >> 2) * stride_u + ((uint32_t) c & 3u) * 16u; };
+	auto f_v = [&](int c) { return (uint64_t) ((uint32_t) c >> 2) * stride_v + ((uint32_t) c & 3u) * 64u; };
+
+	f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+	const f3 light = ld3(a.p.view.light_pos);
+	const bool lit = a.p.light_kd > 0.01f;
+	const float threshold = a.p.ray_threshold;
+	uint64_t live = alive_mask;
+	float k = kx;                                   // the sample being processed (wave-uniform on the column path, per lane on the fallback)
+
+	// explicit fetch of the element pair (march index i, i + 1) of a texel-space position, clamp addressing: any position is in bounds
+	auto fetch_pair = [&](float xb, float yb, float zb, uint32_t &w0, uint32_t &w1) {
+		const int ix = (int) __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x), iy = (int) __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y), iz = (int) __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
+		const uint32_t iu = (uint32_t) (U == 0 ? ix : iy), iv = (uint32_t) (V == 1 ? iy : iz), im = (uint32_t) (M == 0 ? ix : (M == 1 ? iy : iz));
+		const uint32_t wq = __umulhi(im, 0xAAAAAAABu) >> 1, sub = im - wq * 3u;
+		const uint32_t block = ((iv >> 2) * nbu + (iu >> 2)) * nw + wq;
+		const uint8_t *p = copy + (((uint64_t) block << 8) + (iv & 3u) * 64u + (iu & 3u) * 16u + sub * 4u);
+		p = VR_BC_POINTER(a, const uint8_t *, p, 8u);
+		const uint2 both = *(const uint2 *) p;
+		w0 = both.x; w1 = both.y;
+	};
+	// one sample at `k` whose element pair is (w0, w1): the general kernel's body from the transparency test on
+	auto sample = [&](uint32_t w0, uint32_t w1) {
+		if ((__builtin_amdgcn_uicmp((w0 | w1) & a.skip_mask, a.skip_cmp, kIcmpNE) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);                                              // the sample's own segment test
+			const float xb = VR_FMA(k, A.x, B.x), yb = VR_FMA(k, A.y, B.y), zb = VR_FMA(k, A.z, B.z);
+			const float raw = col_resolve<M, kQ8>(w0, w1, a, xb, yb, zb);                              // GPURenderer4.cu:76
+			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+			if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
+				f4 c;
+				{
+					const uint32_t i = (uint32_t) (int) tb;
+					const float w = filter_weight<kQ8>(__builtin_amdgcn_fractf(tb));
+					const f4 c0 = tf_l[i], dc = dtf_l[i];
+					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y); c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
+				}
+				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
+				if (shaded != 0ull) {                                                                  // GPURenderer4.cu:41-51 shade_texture
+					const f3 p3 = march_point<SAMPLING>(origin, dir, k);
+					const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
+					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
+					const float sx = VR_FMA(d.x * inv, a.lh_x, xb), sy = VR_FMA(d.y * inv, a.lh_y, yb), sz = VR_FMA(d.z * inv, a.lh_z, zb);
+					uint32_t l0, l1;
+					fetch_pair(sx, sy, sz, l0, l1);
+					const float raw_l = col_resolve<M, kQ8>(l0, l1, a, sx, sy, sz);
+					const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);
+					c.x += diffuse; c.y += diffuse; c.z += diffuse;
+				}
+				const float t = select_lanes(live, 1 - acc.w);
+				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y); acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
+				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                           // ERT (CPURenderer.cpp:35-36)
+			}
+		}
+	};
+
+	// -- can this wave take the column path?
+	const int leader = __builtin_ctzll(alive_mask);
+	const float kx_l = rlane(kx, leader), Bm_l = rlane(Bm, leader);
+	bool ok = __builtin_amdgcn_ballot_w64(alive && (__float_as_uint(kx) != __float_as_uint(kx_l) || __float_as_uint(Bm) != __float_as_uint(Bm_l))) == 0ull;
+	const float advance = __builtin_fabsf(Am) * step;                       // cells along m per sample: a window is never skipped, and holds at most ~200 samples
+	ok = ok && __builtin_amdgcn_ballot_w64(!(advance >= (1.0f / 64.0f) && advance <= 1.0f)) == 0ull;
+	// lateral cells at the two ends of the segment (the coordinate is monotone in k, so is its cell)
+	auto cell = [&](float kk, float Ac, float Bc, float maxc) { return (int) __builtin_amdgcn_fmed3f(VR_FMA(kk, Ac, Bc), 0.0f, maxc); };
+	int cu0 = cell(kx, Au, Bu, max_u), cv0 = cell(kx, Av, Bv, max_v);
+	int cu1 = cell(ky, Au, Bu, max_u), cv1 = cell(ky, Av, Bv, max_v);
+	{   // lanes without a segment ride along in the leader's column
+		const int lu = __builtin_amdgcn_readlane(cu0, leader), lv = __builtin_amdgcn_readlane(cv0, leader);
+		if (!alive) { cu0 = cu1 = lu; cv0 = cv1 = lv; ky = -1.0f; }
+	}
+	const uint64_t flips_u = __builtin_amdgcn_ballot_w64(cu0 != cu1), flips_v = __builtin_amdgcn_ballot_w64(cv0 != cv1);
+	ok = ok && __builtin_amdgcn_ballot_w64((cu1 - cu0) * (cu1 - cu0) > 1 || (cv1 - cv0) * (cv1 - cv0) > 1) == 0ull;
+	// offsets relative to the leader's column, biased by 2^30 so that they are unsigned 32-bit VGPR offsets of one scalar base
+	const int64_t ref = (int64_t) (f_u(__builtin_amdgcn_readlane(cu0, leader)) + f_v(__builtin_amdgcn_readlane(cv0, leader)));
+	const int64_t rel0 = (int64_t) (f_u(cu0) + f_v(cv0)) - ref;
+	const int64_t du64 = (int64_t) f_u(cu1) - (int64_t) f_u(cu0), dv64 = (int64_t) f_v(cv1) - (int64_t) f_v(cv0);
+	{
+		const int64_t lim = 1ll << 28;
+		ok = ok && __builtin_amdgcn_ballot_w64(rel0 <= -lim || rel0 >= lim || du64 <= -lim || du64 >= lim || dv64 <= -lim || dv64 >= lim) == 0ull;
+	}
+
+	if (ok) {
+		const bool has_flips = (flips_u | flips_v) != 0ull;
+		const uint32_t voff0 = (uint32_t) (rel0 + (1ll << 30));
+		const uint32_t d_u = (uint32_t) du64, d_v = (uint32_t) dv64;            // two's complement deltas: the 32-bit sum wraps back into range
+		uint64_t s_base;
+		{
+			const uint64_t b = (uint64_t) (uintptr_t) copy + (uint64_t) ref - (1ull << 30);
+			s_base = ((uint64_t) rfl((uint32_t) (b >> 32)) << 32) | rfl((uint32_t) b);
+		}
+		// flip thresholds: the smallest float t in (kx, ky] with cell(t) != cell(kx), by bisection over the (positive) float bit patterns
+		float t_u = __builtin_inff(), t_v = __builtin_inff();
+		auto bisect = [&](bool flipping, int c0, float Ac, float Bc, float maxc) {
+			uint32_t lo = __float_as_uint(kx), hi = __float_as_uint(ky);
+			if (!flipping) hi = lo;
+			for (int it = 0; it < 34 && __builtin_amdgcn_ballot_w64(hi - lo > 1u) != 0ull; it++) {
+				const uint32_t mid = lo + ((hi - lo) >> 1);
+				const bool same = cell(__uint_as_float(mid), Ac, Bc, maxc) == c0;
+				if (hi - lo > 1u) { if (same) lo = mid; else hi = mid; }
+			}
+			return flipping ? __uint_as_float(hi) : __builtin_inff();
+		};
+		if (flips_u != 0ull) t_u = bisect(cu0 != cu1, cu0, Au, Bu, max_u);
+		if (flips_v != 0ull) t_v = bisect(cv0 != cv1, cv0, Av, Bv, max_v);
+
+		// -- the wave-uniform sample sequence, 64 samples at a time: lane j of `kvec` holds k of sample n + j, `lcvec` its (logical) cell
+		// along m, `wvec` the window that cell lies in.  The reference forms k by repeated fp32 additions k += step.  Inside one binade
+		// [2^e, 2^(e+1)) every k is a multiple of u = 2^(e-23), and fl(k + step) = k + round_u(step) whatever k is — unless step's part
+		// below u is exactly u / 2 (a tie, broken by k's parity) — so the sequence is an EXACT arithmetic progression there: k_(n+j) =
+		// fma(j, delta, k_n) with delta = fl(k_n + step) - k_n, no rounding (every term is a multiple of u inside the binade).  A batch that
+		// would cross a binade, a tie, or k <= 2^-102 is formed by the 64 sequential additions instead (lane j keeps the j-th sum): a handful
+		// of batches per ray.
+		const float inv_am = 1.0f / Am, span = 3.0f * __builtin_fabsf(inv_am) + 2.0f * step;       // k range one window can cover, with margin
+		const int dsign = (__float_as_uint(comp3<M>(dir)) >> 31) != 0u ? -1 : 1;     // from the kernel argument's bits: stays scalar
+		float kvec = 0.0f, knext = kx_l;
+		int lcvec = 0, wvec = 0;
+		auto refill = [&]() {
+			const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // 0 .. 63
+			const float kbase = knext;
+			const float k1 = kbase + step, delta = k1 - kbase, low = step - delta;           // delta = round_u(step); low = what the rounding dropped (both exact)
+			const uint32_t e = __float_as_uint(kbase) >> 23;                                  // kbase >= 0: the biased exponent
+			const float half_ulp = __uint_as_float((e > 24u ? e - 24u : 1u) << 23);
+			const float kend = VR_FMA(64.0f, delta, kbase);
+			const bool fast = rfl((e > 24u && (__float_as_uint(kend) >> 23) == e && __builtin_fabsf(low) != half_ulp && delta > 0.0f) ? 1u : 0u) != 0u;
+			if (fast) {
+				kvec = VR_FMA((float) lane_i, delta, kbase);
+				knext = uni(kend);
+			} else {
+				float kc = kbase;
+				#pragma nounroll
+				for (uint32_t j = 0; j < 64u; j++) { kvec = lane_i == j ? kc : kvec; kc = kc + step; }
+				knext = uni(kc);
+			}
+			lcvec = (int) VR_FMA(kvec, Am, Bm_l);                                            // truncation; may leave 0 .. Nm-1 past the exit
+			// window index = floor(cell / 3), also for the cells below 0 a ray reaches after its exit (biased by a multiple of 3; a cell index
+			// that must never stick to a window: the loops below end when the samples have moved on)
+			wvec = (int) (__umulhi((uint32_t) lcvec + 0x30000000u, 0xAAAAAAABu) >> 1) - 0x10000000;
+		};
+		refill();
+		int pos = 0;                                                        // next sample of the batch
+		int cur = __builtin_amdgcn_readlane(wvec, 0);                       // the window being consumed (0 .. nw-1 for the first sample of a live ray)
+		cur = cur < 0 ? 0 : (cur > (int) nw - 1 ? (int) nw - 1 : cur);
+		// Hang / bounds guard: a ray cannot need more windows than lie ahead of its first one in march direction; past the last of them
+		// every k exceeds every ky and `live` empties at the next rotation, i.e. at most 2 * kColSlots windows later.  Those — and the
+		// kColDepth prefetched beyond — are read without a clamp: neighbouring blocks' windows, or the kColPadBytes of zeroes at both
+		// ends of the copy (64 windows).
+		static_assert(2 * kColSlots + kColDepth + 4 <= 64, "kColPadBytes");
+		int guard = (dsign > 0 ? (int) nw - cur : cur + 1) + 2 * kColSlots;
+		uint64_t wa = s_base + (uint64_t) (uint32_t) cur * kColBlockBytes;      // address (before the lane offset) of the window being ISSUED
+		const uint64_t wa_step = (uint64_t) (int64_t) (dsign * (int) kColBlockBytes);
+		int wi = cur;                                                       // its index (only the flip logic needs it)
+		auto march = [&](auto flips_tag) {
+			constexpr bool kFlips = decltype(flips_tag)::value;
+			// the k at which window W begins, predicted from the coordinate along m (any deterministic function of W is CORRECT — issue and
+			// consumption evaluate the same one; its accuracy only decides how often a window turns careful)
+			auto k_pred = [&](int W) { return ((float) (dsign > 0 ? 3 * W : 3 * W + 3) - Bm_l) * inv_am; };
+			auto issue = [&](u32x4 &dst) {
+				uint32_t vo = voff0;
+				if (kFlips) {
+					const float kp = k_pred(wi);
+					vo += (kp >= t_u ? d_u : 0u) + (kp >= t_v ? d_v : 0u);
+					wi += dsign;
+				}
+#ifdef VR_BOUNDS_CHECK
+				(void) VR_BC_ADDRESS(a, wa + vo, 16u);
+#endif
+#ifdef VR_COL_EXP_NO_LOAD              // timing-only experiment: no gathers
+				dst = (u32x4) (vo & 0u);
+#else
+				managed_load128_s(dst, vo, wa);
+#endif
+				wa += wa_step;
+			};
+			u32x4 slot[kColSlots];
+			slot[kColSlots - 1] = (u32x4) (0u);
+			static_for<0, kColDepth>([&](auto j) { issue(slot[j.value]); });
+			auto window_step = [&](auto jc) {
+				constexpr int c = decltype(jc)::value, n = (c + kColDepth) % kColSlots;
+				issue(slot[n]);
+				__builtin_amdgcn_sched_barrier(0);
+				pin(slot[c]); managed_wait<kColDepth>(); pin(slot[c]);
+				const u32x4 o = slot[c];
+				if (c == 0) live &= __builtin_amdgcn_fcmpf(rlane(kvec, pos), ky, kFcmpOLE);      // lazy exit test: once per rotation of the slots (and by every sample that composites)
+				bool careful = false;
+				if (kFlips) {
+					// no lane's threshold in (min(k, kp), max(k + span, kp)]: the state a lane's column was issued for holds for every sample of the window
+					const float kf = rlane(kvec, pos), kp = k_pred(cur), lo = __builtin_fminf(kf, kp), hi = __builtin_fmaxf(kf + span, kp);
+					careful = __builtin_amdgcn_ballot_w64((t_u > lo && t_u <= hi) || (t_v > lo && t_v <= hi)) != 0ull;
+				}
+				const uint32_t all4 = (o.x | o.y | o.z | o.w) & a.skip_mask;
+				bool dense = careful;
+#ifndef VR_COL_EXP_NO_DENSE           // (timing-only experiment: every window counts as transparent)
+				if ((__builtin_amdgcn_uicmp(all4, a.skip_cmp, kIcmpNE) & live) != 0ull) dense = dense || VR_OPEN_LANES(acc.w, live) != 0ull;
+#endif
+				if (!dense) {
+					// a transparent window: its samples — consecutive lanes of the batch, from pos — just pass.  A window holds at most 3 * 64 + 1
+					// samples (a sample advances >= 1/64 cell, checked above), i.e. it ends within four batches: the bound is a hang guard
+					for (int batches = 0; batches < 5; batches++) {
+						pos += __builtin_popcountll(__builtin_amdgcn_ballot_w64(wvec == cur));
+						if (pos < 64) break;
+						refill(); pos = 0;                                 // the window may go on in the next batch
+					}
+					pos = pos < 64 ? pos : 63;
+				} else {
+					const uint32_t first = (uint32_t) (cur * 3);
+					for (int batches = 0; batches < 5; batches++) {
+						const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wvec == cur));
+						for (int i = pos; i < pos + cnt; i++) {
+							k = rlane(kvec, i);
+							uint32_t w0, w1;
+							if (kFlips && careful) fetch_pair(VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), w0, w1);      // each lane's true column
+							else {
+								const uint32_t sub = (uint32_t) __builtin_amdgcn_readlane(lcvec, i) - first;
+								w0 = sub == 0u ? o.x : (sub == 1u ? o.y : o.z); w1 = sub == 0u ? o.y : (sub == 1u ? o.z : o.w);
+							}
+							sample(w0, w1);
+						}
+						pos += cnt;
+						if (pos < 64) break;
+						refill(); pos = 0;
+					}
+					pos = pos < 64 ? pos : 63;
+				}
+				cur += dsign;
+			};
+			while (live != 0ull && guard > 0) {
+				static_for<0, kColSlots>(window_step);
+				guard -= kColSlots;
+			}
+			static_for<0, kColSlots>([&](auto j) { pin(slot[j.value]); });
+			managed_wait<0>();
+			static_for<0, kColSlots>([&](auto j) { pin(slot[j.value]); });
+		};
+		if (has_flips) march(std::true_type()); else march(std::false_type());
+	} else {
+		// per-lane march with explicit fetches (exact, unpipelined): the few waves that straddle two kx values, and forced testing
+		while (live != 0ull) {
+			uint32_t w0, w1;
+			fetch_pair(VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), w0, w1);
+			sample(w0, w1);
+			k += step;
+			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);
+		}
+	}
+	uint32_t rgba = 0;
+	if (hit) rgba = map_float_int(acc.x, 256) | (map_float_int(acc.y, 256) << 8) | (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
+	if (in_frame) out[out_index] = rgba;
+}
+
 // Which instantiation a frame runs: ONE selector, visited by the launcher and by the host's questions about the launch (does it read
 // the linear array?  how many workgroup tiles?), so the answers cannot drift from what is launched.  `visit` is called with four
 // std::integral_constant tags <SAMPLING, BPV, ADDR, LAYOUT> and a bool: true = the variant reads `linear`, false = the brick copy.
@@ -1107,6 +1473,12 @@ template <int ADDR, int LAYOUT> constexpr uint32_t variant_threads() { return Lu
 
 // what launch_raymarch will do with these arguments (launch_frame asks before it launches)
 RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t bpv) {
+	if (have_bricked && a.layout == kLayoutColumn) {                     // colmarch_kernel: 512 threads = 32x16 pixels
+		RaymarchPlan plan;
+		plan.reads_linear = false;
+		plan.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u; plan.tiles_y = (a.p.out_rows + a.phase_y + 15u) / 16u;
+		return plan;
+	}
 	return select_variant(a, have_bricked, bpv, [&](auto, auto, auto addr, auto layout, bool reads_linear) {
 		constexpr uint32_t threads = variant_threads<decltype(addr)::value, decltype(layout)::value>();
 		RaymarchPlan plan;
@@ -1119,6 +1491,17 @@ RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t b
 
 hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const void *bricked, uint32_t bpv, const float *tf,
                            const uint32_t *esl, void *out, TileSchedule sched, hipStream_t stream) {
+	if (bricked != nullptr && args.layout == kLayoutColumn) {            // orthogonal view along args.col_axis, full march, TRILINEAR, 1-byte voxels (launch_frame)
+		RayKernelArgs a = args;
+		a.tiles_x = (a.p.out_width + a.phase_x + 31u) / 32u; a.tiles_y = (a.p.out_rows + a.phase_y + 15u) / 16u;
+		const dim3 grid(a.tiles_x * a.tiles_y), block(512);
+		const bool q8 = a.p.sampling == VR_SAMPLE_TRILINEAR_Q8;
+		auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, a, (const uint8_t *) bricked, tf, (uint32_t *) out); };
+		if (a.col_axis == 0u) { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 0>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 0>); }
+		else if (a.col_axis == 1u) { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 1>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 1>); }
+		else { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 2>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 2>); }
+		return hipGetLastError();
+	}
 	return select_variant(args, bricked != nullptr, bpv, [&](auto sampling, auto voxel, auto addr, auto layout, bool reads_linear) {
 		constexpr int SAMPLING = decltype(sampling)::value, BPV = decltype(voxel)::value, ADDR = decltype(addr)::value, LAYOUT = decltype(layout)::value;
 		constexpr uint32_t threads = variant_threads<ADDR, LAYOUT>();
@@ -1357,6 +1740,84 @@ hipError_t launch_brickify_voxel(const void *linear, void *voxel_bricks, uint32_
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
 	if (run_layout == kLayoutRunY) return launch_strip<1, kBuildRunY, kPlaneXY>(linear, run_copy, dim_x, dim_y, dim_z, stream);
 	return launch_strip<1, kBuildRunZ, kPlaneXY>(linear, run_copy, dim_x, dim_y, dim_z, stream);
+}
+
+// ---- linear -> column windows (kLayoutColumn): LDS-tiled like the brick strips --------------------------------------------------------
+// A workgroup owns NBU lateral blocks (4x4 cell columns each) side by side along u, one block row along v, and NW consecutive windows along
+// the march axis m.  It stages the (4 NBU + 1) x 5 x (3 NW + 1) voxels those windows are made of (+1 neighbours, every index clamped at
+// the upper faces, where the interpolation weight is exactly 0) with loads that are contiguous along x — x is u for m = y, z and the march
+// axis itself for m = x, hence the two tile shapes — then writes the windows with 16-byte stores in copy order: thread t -> (block, window,
+// column), 256 contiguous bytes per (block, window), a block's windows back to back.  Bound: HBM, bytes = linear + copy.
+template <int M> struct ColBuildCfg {
+	static constexpr uint32_t nbu = M == 0 ? 4u : 32u, nwin = M == 0 ? 85u : 8u;
+	static constexpr uint32_t tu = 4u * nbu + 1u, tv = 5u, te = kColCells * nwin + 1u;
+	static constexpr uint32_t tx = M == 0 ? te : tu;                           // tile extent along x (the contiguous axis of the linear array)
+	static constexpr uint32_t pitch = (tx + 3u) / 4u * 4u + 4u;               // bytes per staged x-row (multiple of 4, rows shifted over the banks)
+	static constexpr uint32_t rows = M == 0 ? tu * tv : tv * te;              // staged rows
+};
+
+template <int M>
+__global__ __launch_bounds__(256)
+void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
+	typedef ColBuildCfg<M> S;
+	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
+	__shared__ __attribute__((aligned(16))) uint8_t tile[S::rows * S::pitch];
+	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
+	const uint32_t nbu = (dim[U] + 3u) >> 2, nw = col_windows(dim[M]);
+	const uint32_t bu0 = blockIdx.x * S::nbu, bv = blockIdx.y, w0 = blockIdx.z * S::nwin;
+	const uint32_t u0 = bu0 * 4u, v0 = bv * 4u, e0 = w0 * kColCells;
+	const uint32_t t = threadIdx.x;
+	// row r of the tile: m = y, z: r = dv * te + de holds u = u0 ..; m = x: r = dv * tu + du holds e = e0 ..  (x runs along the row either way)
+	auto row_of = [&](uint32_t du, uint32_t dv, uint32_t de) { return M == 0 ? dv * S::tu + du : dv * S::te + de; };
+	auto at = [&](uint32_t du, uint32_t dv, uint32_t de) -> uint32_t { return tile[row_of(du, dv, de) * S::pitch + (M == 0 ? de : du)]; };
+	{
+		const uint32_t x0 = M == 0 ? e0 : u0;
+		const bool words = dim_x % 4u == 0u && ((uintptr_t) lin & 3u) == 0u;
+		constexpr uint32_t wpr = (S::tx + 3u) / 4u;                           // dwords per row (the last one may be partial)
+		for (uint32_t i = t; i < S::rows * wpr; i += 256u) {
+			const uint32_t r = i / wpr, cw = i - r * wpr;
+			uint32_t y, z;                                                    // the row's two coordinates, clamped at the upper faces
+			if (M == 2) { y = v0 + r / S::te; z = e0 + r % S::te; }
+			else if (M == 1) { z = v0 + r / S::te; y = e0 + r % S::te; }
+			else { z = v0 + r / S::tu; y = u0 + r % S::tu; }
+			y = y < dim_y ? y : dim_y - 1u; z = z < dim_z ? z : dim_z - 1u;
+			const uint8_t *src = lin + ((uint64_t) z * dim_y + y) * dim_x;
+			const uint32_t x = x0 + cw * 4u;
+			uint32_t word;
+			if (words && x + 3u < dim_x) word = *(const uint32_t *) (src + x);
+			else {
+				word = 0u;
+				for (uint32_t j = 0; j < 4u; j++) { const uint32_t xx = x + j < dim_x ? x + j : dim_x - 1u; word |= (uint32_t) src[xx] << (8u * j); }
+			}
+			*(uint32_t *) (tile + r * S::pitch + cw * 4u) = word;
+		}
+	}
+	__syncthreads();
+	const uint32_t blocks_here = nbu - bu0 < S::nbu ? nbu - bu0 : S::nbu, wins_here = nw - w0 < S::nwin ? nw - w0 : S::nwin;
+	for (uint32_t i = t; i < blocks_here * wins_here * 16u; i += 256u) {
+		const uint32_t col = i & 15u, bw = i >> 4, w = bw % wins_here, b = bw / wins_here;
+		const uint32_t du = b * 4u + (col & 3u), dv = col >> 2;
+		uint32_t word[4];
+		#pragma unroll
+		for (uint32_t j = 0; j < 4u; j++) {
+			// element 3w + j, march index clamped at Nm - 1 (tile-relative: the staged index of the clamped element)
+			uint32_t e = e0 + w * kColCells + j;
+			if (e > dim[M] - 1u) e = dim[M] - 1u;
+			const uint32_t de = e - e0;
+			word[j] = at(du, dv, de) | (at(du + 1u, dv, de) << 8) | (at(du, dv + 1u, de) << 16) | (at(du + 1u, dv + 1u, de) << 24);
+		}
+		out[((uint64_t) ((uint64_t) bv * nbu + bu0 + b) * nw + w0 + w) * 16u + col] = make_uint4(word[0], word[1], word[2], word[3]);
+	}
+}
+
+hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
+	const uint32_t nbu = (dim[col_axis_u(axis)] + 3u) / 4u, nbv = (dim[col_axis_v(axis)] + 3u) / 4u, nw = col_windows(dim[axis]);
+	auto grid = [&](uint32_t per_u, uint32_t per_w) { return dim3((nbu + per_u - 1u) / per_u, nbv, (nw + per_w - 1u) / per_w); };
+	if (axis == 0) hipLaunchKernelGGL(column_build_kernel<0>, grid(ColBuildCfg<0>::nbu, ColBuildCfg<0>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
+	else if (axis == 1) hipLaunchKernelGGL(column_build_kernel<1>, grid(ColBuildCfg<1>::nbu, ColBuildCfg<1>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
+	else hipLaunchKernelGGL(column_build_kernel<2>, grid(ColBuildCfg<2>::nbu, ColBuildCfg<2>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
+	return hipGetLastError();
 }
 
 // ---- feeders: per-ESL-block min/max (RaycasterBase.cpp:101-117) as an HBM-streaming reduction --------------------------
