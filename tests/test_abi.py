@@ -83,6 +83,17 @@ def test_hot_kernels_keep_eight_waves_per_simd(vr):
     # quad bricks {NEAREST, TRILINEAR, Q8} x {u8, u16} x {32-bit, 64-bit z tables} = 12, voxel bricks (NEAREST) x 2 x 2 = 4,
     # run bricks {z, y, both per tile} x {TRILINEAR, Q8} (u8, 32-bit) = 6, oct bricks {TRILINEAR, Q8} (u16) x {32-bit, 64-bit z tables} = 4
     assert found == 26, found
+    # the column march (colmarch_kernel<SAMPLING, axis, FLIPS>): {TRILINEAR, Q8} x {x, y, z} x {with, without the flip logic} = 12 kernels, none
+    # may spill — a spilled scalar or vector register is reloaded inside the window loop behind an s_waitcnt that drains the prefetch
+    # pipeline, and a build that was FORCED to 8 waves by spilling faulted on the GPU (round 4)
+    found = 0
+    for m in re.finditer(r"Function Name: (\S*colmarch_kernelILi\dELi\dELb[01]E\S*).*?TotalSGPRs: (\d+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
+                         r"SGPRs Spill: (\d+).*?VGPRs Spill: (\d+)", text, flags=re.S):
+        sgprs, vgprs, scratch, sspill, vspill = (int(m.group(i)) for i in (2, 3, 4, 5, 6))
+        found += 1
+        assert scratch == 0 and sspill == 0 and vspill == 0, (m.group(1), "spills", scratch, sspill, vspill)
+        assert sgprs <= 80 and vgprs <= 64, (m.group(1), sgprs, vgprs)
+    assert found == 12, found
 
 
 def _disassemble_gfx950(lib_path, tmp_path):

@@ -65,6 +65,6 @@ def test_parity_suite_under_the_bounds_checked_build():
     with the checked library: every frame still equals the oracle and none reports a violation (a violation fails the frame: VrError)."""
     env = dict(os.environ, VR_HIP_LIB=LIB)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_random.py"), os.path.join(ROOT, "tests", "test_gpu_parity.py"),
-                        "-m", "gpu", "-x", "-q", "-k", "random or layouts_agree or u16 or tile_scheduling or long_thin"],
+                        "-m", "gpu", "-x", "-q", "-k", "random or layouts_agree or column or u16 or tile_scheduling or long_thin"],
                        capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1078,10 +1078,10 @@ __device__ __forceinline__ float rlane(float v, int lane) { return __uint_as_flo
 // the eight corner voxels of a sample out of the two quad elements along m (w0 = march index i, w1 = i + 1) -> trilinear value;
 // element bytes are (u,v), (u+1,v), (u,v+1), (u+1,v+1) with (u,v) the lateral axes of m in increasing order; lerps in x, y, z order
 template <int M, bool Q8>
-__device__ __forceinline__ float col_resolve(uint32_t w0, uint32_t w1, const RayKernelArgs &a, float xb, float yb, float zb) {
-	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x)));
-	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y)));
-	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z)));
+__device__ __forceinline__ float col_resolve(uint32_t w0, uint32_t w1, float max_x, float max_y, float max_z, float xb, float yb, float zb) {
+	const float ax = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(xb, 0.0f, max_x)));
+	const float ay = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(yb, 0.0f, max_y)));
+	const float az = filter_weight<Q8>(__builtin_amdgcn_fractf(__builtin_amdgcn_fmed3f(zb, 0.0f, max_z)));
 	const float p0 = (float) (w0 & 0xffu), p1 = (float) ((w0 >> 8) & 0xffu), p2 = (float) ((w0 >> 16) & 0xffu), p3 = (float) (w0 >> 24);
 	const float q0 = (float) (w1 & 0xffu), q1 = (float) ((w1 >> 8) & 0xffu), q2 = (float) ((w1 >> 16) & 0xffu), q3 = (float) (w1 >> 24);
 	float v000, v100, v010, v110, v001, v101, v011, v111;
@@ -1094,14 +1094,18 @@ __device__ __forceinline__ float col_resolve(uint32_t w0, uint32_t w1, const Ray
 	return lerp(c0, c1, az);
 }
 
-template <int SAMPLING, int M>
+// FLIPS: the instantiation that follows lanes through a change of their cell column (views whose direction carries rounding noise
+// in its lateral components); without it (lateral components exactly 0: no lane can flip — the host decides) a wave that does flip
+// marches per lane.  Two kernels rather than two loops in one: each stays inside 64 VGPRs / 80 SGPRs without spilling.
+template <int SAMPLING, int M, bool FLIPS>
 #ifndef VR_COL_WAVES
-#define VR_COL_WAVES 8
+#define VR_COL_WAVES 4
 #endif
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(VR_COL_WAVES, VR_COL_WAVES)))       // 64 VGPRs at 8 waves per SIMD (prefetch depth 3)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(VR_COL_WAVES, 8)))       // 8 waves per SIMD wanted (64 VGPRs, 80 SGPRs), never by spilling: tests/test_abi.py checks the built kernels
 void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, const float *__restrict__ tf_g, uint32_t *__restrict__ out) {
 	constexpr bool kQ8 = SAMPLING == VR_SAMPLE_TRILINEAR_Q8;
 	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
+	typedef const RayKernelArgs __attribute__((address_space(4))) *ConstArgs;
 	__shared__ f4 tf_l[VR_TF_SIZE + 1], dtf_l[VR_TF_SIZE + 1];
 	{
 		const uint32_t t = threadIdx.x;
@@ -1130,26 +1134,28 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	const uint32_t band = ly / a.p.band_rows;
 	const uint32_t gy = (band * a.p.band_stride + a.p.band_first) * a.p.band_rows + (ly - band * a.p.band_rows);
 	const uint32_t gx = a.p.x0 + lx;
-	const uint32_t out_index = ly * a.p.out_width + lx;                      // (frames are at most 65535 x 65535 pixels, validate_params; < 2^32 for in-frame lanes)
+	// where the pixel goes: 0xffffffff for lanes outside the buffer (frames are at most 65535 x 65535 pixels, validate_params: every real index is smaller)
+	uint32_t out_index = in_frame ? ly * a.p.out_width + lx : 0xffffffffu;
 
 	// -- View::get_ray (ViewBase.h:23-35), orthogonal branch only (the host never launches this kernel for a perspective view)
 	bool alive = in_frame && gx < a.p.view.width && gy < a.p.view.height;
 	const f3 dir = ld3(a.p.view.direction);
-	f3 origin;
-	{
-		const f3 vo = ld3(a.p.view.origin), vr_ = ld3(a.p.view.right_plane), vu = ld3(a.p.view.up_plane);
-		const float fx = (float) ((int) gx - (int) (a.p.view.width / 2u)), fy = (float) ((int) gy - (int) (a.p.view.height / 2u));
-		origin = mk3(vo.x + vr_.x * fx, vo.y + vr_.y * fx, vo.z + vr_.z * fx);
-		origin = mk3(origin.x + vu.x * fy, origin.y + vu.y * fy, origin.z + vu.z * fy);
-	}
+	// (the march keeps the frame pixel in ONE register and forms the ray origin again for the few samples that are shaded: two registers less)
+	uint32_t pixel = (gy << 16) | (gx & 0xffffu);
+	auto origin_of = [](ConstArgs q, uint32_t px) {
+		const float fx = (float) ((int) (px & 0xffffu) - (int) (q->p.view.width / 2u)), fy = (float) ((int) (px >> 16) - (int) (q->p.view.height / 2u));
+		f3 o = mk3(q->p.view.origin[0] + q->p.view.right_plane[0] * fx, q->p.view.origin[1] + q->p.view.right_plane[1] * fx, q->p.view.origin[2] + q->p.view.right_plane[2] * fx);
+		return mk3(o.x + q->p.view.up_plane[0] * fy, o.y + q->p.view.up_plane[1] * fy, o.z + q->p.view.up_plane[2] * fy);
+	};
+	const f3 origin = origin_of((ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(), pixel);
 	float kx = 0, ky = 0;
 	alive = alive && intersect(origin, dir, kx, ky);
 	const float step = a.p.ray_step;
 	alive = alive && (ky + step > ky);                                       // termination guard (see raymarch_kernel)
 	ky = flmin(ky, kx + step * (float) kMaxRaySteps);
-	const bool hit = alive;
 	const uint64_t alive_mask = __builtin_amdgcn_ballot_w64(alive);
 	if (alive_mask == 0ull) { if (in_frame) out[out_index] = 0u; return; }
+	if (!alive) ky = -1.0f;                                                  // (also what the final store reads "no segment" from)
 
 	// texel-space ray (oracle/vr_oracle.c axis_setup): coordinate = fma(k, A, B); A is wave-uniform (orthogonal view)
 	// (the same value in every lane, formed by the vector unit: moved to scalar registers so that it does not occupy three VGPRs for the whole march)
@@ -1158,7 +1164,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	const f3 B = mk3(VR_FMA(origin.x, a.half_x, a.off_x), VR_FMA(origin.y, a.half_y, a.off_y), VR_FMA(origin.z, a.half_z, a.off_z));
 	const float Am = comp3<M>(A), Au = comp3<U>(A), Av = comp3<V>(A);
 	const float Bm = comp3<M>(B), Bu = comp3<U>(B), Bv = comp3<V>(B);
-	const uint32_t dim_u = U == 0 ? a.dim_x : a.dim_y, dim_v = V == 1 ? a.dim_y : a.dim_z, dim_m = M == 0 ? a.dim_x : (M == 1 ? a.dim_y : a.dim_z);
+	const uint32_t dim_u = U == 0 ? a.dim_x : a.dim_y, dim_m = M == 0 ? a.dim_x : (M == 1 ? a.dim_y : a.dim_z);
 	const float max_u = U == 0 ? a.max_x : a.max_y, max_v = V == 1 ? a.max_y : a.max_z;
 	const uint32_t nbu = (dim_u + 3u) >> 2, nw = col_windows(dim_m);
 	const uint64_t stride_u = (uint64_t) nw * kColBlockBytes, stride_v = (uint64_t) nbu * stride_u;       // bytes between lateral blocks
@@ -1166,31 +1172,57 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	auto f_v = [&](int c) { return (uint64_t) ((uint32_t) c >> 2) * stride_v + ((uint32_t) c & 3u) * 64u; };
 
 	f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
-	const f3 light = ld3(a.p.view.light_pos);
-	const bool lit = a.p.light_kd > 0.01f;
-	const float threshold = a.p.ray_threshold;
 	uint64_t live = alive_mask;
 	float k = kx;                                   // the sample being processed (wave-uniform on the column path, per lane on the fallback)
 
+	// The transparent march runs on a dozen scalars; everything else the DENSE path needs (clamp bounds, shading constants, the light,
+	// the view direction) is read again from the kernel-argument segment where it is used, through a pointer the compiler cannot see
+	// through — kept live across the march those ~25 scalars push the kernel past the 80 SGPRs that 8 waves per SIMD allow, and the
+	// compiler then spills scalars into VGPR lanes inside the window loop (RayKernelArgs is the first argument: offset 0).
+	auto dense_args = []() { ConstArgs q = (ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+	struct KernelArguments { RayKernelArgs a; const uint8_t *copy; const float *tf_g; uint32_t *out; };      // the kernel's parameter list as it lies in that segment
+	typedef const KernelArguments __attribute__((address_space(4))) *ConstKernelArguments;
 	// explicit fetch of the element pair (march index i, i + 1) of a texel-space position, clamp addressing: any position is in bounds
-	auto fetch_pair = [&](float xb, float yb, float zb, uint32_t &w0, uint32_t &w1) {
-		const int ix = (int) __builtin_amdgcn_fmed3f(xb, 0.0f, a.max_x), iy = (int) __builtin_amdgcn_fmed3f(yb, 0.0f, a.max_y), iz = (int) __builtin_amdgcn_fmed3f(zb, 0.0f, a.max_z);
+	auto pair_address = [&](ConstArgs q, float xb, float yb, float zb) {
+		const int ix = (int) __builtin_amdgcn_fmed3f(xb, 0.0f, q->max_x), iy = (int) __builtin_amdgcn_fmed3f(yb, 0.0f, q->max_y), iz = (int) __builtin_amdgcn_fmed3f(zb, 0.0f, q->max_z);
 		const uint32_t iu = (uint32_t) (U == 0 ? ix : iy), iv = (uint32_t) (V == 1 ? iy : iz), im = (uint32_t) (M == 0 ? ix : (M == 1 ? iy : iz));
 		const uint32_t wq = __umulhi(im, 0xAAAAAAABu) >> 1, sub = im - wq * 3u;
-		const uint32_t block = ((iv >> 2) * nbu + (iu >> 2)) * nw + wq;
-		const uint8_t *p = copy + (((uint64_t) block << 8) + (iv & 3u) * 64u + (iu & 3u) * 16u + sub * 4u);
-		p = VR_BC_POINTER(a, const uint8_t *, p, 8u);
-		const uint2 both = *(const uint2 *) p;
+		const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
+		const uint32_t block = ((iv >> 2) * ((qdim_u + 3u) >> 2) + (iu >> 2)) * col_windows(qdim_m) + wq;
+		const uint8_t *p = ((ConstKernelArguments) q)->copy + (((uint64_t) block << 8) + (iv & 3u) * 64u + (iu & 3u) * 16u + sub * 4u);
+		return VR_BC_POINTER(a, const uint8_t *, p, 8u);
+	};
+	auto fetch_pair = [&](ConstArgs q, float xb, float yb, float zb, uint32_t &w0, uint32_t &w1) {
+		const uint2 both = *(const uint2 *) pair_address(q, xb, yb, zb);
 		w0 = both.x; w1 = both.y;
+	};
+	auto coords = [&](ConstArgs q, float kk, float &xb, float &yb, float &zb) {          // fma(k, A, B) with A = direction * N/2 (the same product, bit for bit)
+		xb = VR_FMA(kk, q->p.view.direction[0] * q->half_x, B.x); yb = VR_FMA(kk, q->p.view.direction[1] * q->half_y, B.y); zb = VR_FMA(kk, q->p.view.direction[2] * q->half_z, B.z);
+	};
+	auto fetch_at = [&](float kk, uint32_t &w0, uint32_t &w1) {                           // the element pair of the sample at kk, from each lane's true column
+		ConstArgs q = dense_args();
+		float xb, yb, zb;
+		coords(q, kk, xb, yb, zb);
+		fetch_pair(q, xb, yb, zb, w0, w1);
+	};
+	// the same as a MANAGED gather (the compiler does not see it: a load it knows to be in flight across the window loop's back edge makes
+	// it put s_waitcnt vmcnt(0) in front of every window gather, and the prefetch pipeline is gone): wait with managed_wait<0>() before use
+	auto fetch_at_managed = [&](float kk, uint64_t &both) {
+		ConstArgs q = dense_args();
+		float xb, yb, zb;
+		coords(q, kk, xb, yb, zb);
+		managed_load64(both, (uint64_t) (uintptr_t) pair_address(q, xb, yb, zb));
 	};
 	// one sample at `k` whose element pair is (w0, w1): the general kernel's body from the transparency test on
 	auto sample = [&](uint32_t w0, uint32_t w1) {
 		if ((__builtin_amdgcn_uicmp((w0 | w1) & a.skip_mask, a.skip_cmp, kIcmpNE) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+			ConstArgs q = dense_args();
 			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);                                              // the sample's own segment test
-			const float xb = VR_FMA(k, A.x, B.x), yb = VR_FMA(k, A.y, B.y), zb = VR_FMA(k, A.z, B.z);
-			const float raw = col_resolve<M, kQ8>(w0, w1, a, xb, yb, zb);                              // GPURenderer4.cu:76
-			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, a.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-			if ((__builtin_amdgcn_fcmpf(tb, a.tf_zero_below, kFcmpOGE) & live) != 0ull) {
+			float xb, yb, zb;
+			coords(q, k, xb, yb, zb);
+			const float raw = col_resolve<M, kQ8>(w0, w1, q->max_x, q->max_y, q->max_z, xb, yb, zb);     // GPURenderer4.cu:76
+			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, q->tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+			if ((__builtin_amdgcn_fcmpf(tb, q->tf_zero_below, kFcmpOGE) & live) != 0ull) {
 				f4 c;
 				{
 					const uint32_t i = (uint32_t) (int) tb;
@@ -1198,21 +1230,23 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 					const f4 c0 = tf_l[i], dc = dtf_l[i];
 					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y); c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
 				}
-				const uint64_t shaded = lit ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
+				const uint64_t shaded = q->p.light_kd > 0.01f ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
 				if (shaded != 0ull) {                                                                  // GPURenderer4.cu:41-51 shade_texture
-					const f3 p3 = march_point<SAMPLING>(origin, dir, k);
-					const f3 d = mk3(light.x - p3.x, light.y - p3.y, light.z - p3.z);
+					const f3 qdir = mk3(q->p.view.direction[0], q->p.view.direction[1], q->p.view.direction[2]);
+					pin(pixel);
+					const f3 p3 = march_point<SAMPLING>(origin_of(q, pixel), qdir, k);
+					const f3 d = mk3(q->p.view.light_pos[0] - p3.x, q->p.view.light_pos[1] - p3.y, q->p.view.light_pos[2] - p3.z);
 					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-					const float sx = VR_FMA(d.x * inv, a.lh_x, xb), sy = VR_FMA(d.y * inv, a.lh_y, yb), sz = VR_FMA(d.z * inv, a.lh_z, zb);
+					const float sx = VR_FMA(d.x * inv, q->lh_x, xb), sy = VR_FMA(d.y * inv, q->lh_y, yb), sz = VR_FMA(d.z * inv, q->lh_z, zb);
 					uint32_t l0, l1;
-					fetch_pair(sx, sy, sz, l0, l1);
-					const float raw_l = col_resolve<M, kQ8>(l0, l1, a, sx, sy, sz);
-					const float diffuse = select_lanes(shaded, (raw_l - raw) * a.kd_scaled);
+					fetch_pair(q, sx, sy, sz, l0, l1);
+					const float raw_l = col_resolve<M, kQ8>(l0, l1, q->max_x, q->max_y, q->max_z, sx, sy, sz);
+					const float diffuse = select_lanes(shaded, (raw_l - raw) * q->kd_scaled);
 					c.x += diffuse; c.y += diffuse; c.z += diffuse;
 				}
 				const float t = select_lanes(live, 1 - acc.w);
 				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y); acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
-				live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                           // ERT (CPURenderer.cpp:35-36)
+				live &= ~__builtin_amdgcn_fcmpf(acc.w, q->p.ray_threshold, kFcmpOGT);                  // ERT (CPURenderer.cpp:35-36)
 			}
 		}
 	};
@@ -1242,17 +1276,36 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		ok = ok && __builtin_amdgcn_ballot_w64(rel0 <= -lim || rel0 >= lim || du64 <= -lim || du64 >= lim || dv64 <= -lim || dv64 >= lim) == 0ull;
 	}
 
+	const bool has_flips = (flips_u | flips_v) != 0ull;
+	// per-lane march with explicit fetches (exact, unpipelined): the few waves that straddle two kx values, and forced testing
+	auto per_lane_march = [&]() {
+		while (live != 0ull) {
+			uint32_t w0, w1;
+			fetch_at(k, w0, w1);
+			sample(w0, w1);
+			k += step;
+			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);
+		}
+	};
 	if (ok) {
-		const bool has_flips = (flips_u | flips_v) != 0ull;
 		const uint32_t voff0 = (uint32_t) (rel0 + (1ll << 30));
-		const uint32_t d_u = (uint32_t) du64, d_v = (uint32_t) dv64;            // two's complement deltas: the 32-bit sum wraps back into range
 		uint64_t s_base;
 		{
 			const uint64_t b = (uint64_t) (uintptr_t) copy + (uint64_t) ref - (1ull << 30);
 			s_base = ((uint64_t) rfl((uint32_t) (b >> 32)) << 32) | rfl((uint32_t) b);
 		}
-		// flip thresholds: the smallest float t in (kx, ky] with cell(t) != cell(kx), by bisection over the (positive) float bit patterns
-		float t_u = __builtin_inff(), t_v = __builtin_inff();
+		const int dsign = (__float_as_uint(comp3<M>(dir)) >> 31) != 0u ? -1 : 1;     // march direction along m, from the kernel argument's bits: stays scalar
+		// window index = floor(cell / 3), also for the cells below 0 a ray reaches after its exit (biased by a multiple of 3; a cell index
+		// must never stick to a window: the loops below end when the samples have moved on)
+		auto window_of = [](int lc) { return (int) (__umulhi((uint32_t) lc + 0x30000000u, 0xAAAAAAABu) >> 1) - 0x10000000; };
+		// Column flips.  A lane's lateral cell changes at the smallest float t in (kx, ky] with cell(t) != cell(kx) (bisection over the
+		// positive float bit patterns, once per ray).  What the march needs of t is only the WINDOW Wt the position k = t lies in: the
+		// coordinate along m and its cell are monotone in k, so every sample in a window before Wt (in march order) has k < t — the lane
+		// still reads its first column — and every sample in a window after Wt has k >= t — its second column; only window Wt itself
+		// can hold samples of both kinds (a "careful" window: every sample fetches from each lane's true column, explicitly).  Windows are
+		// compared through keys that grow by one per window in march order: key = dsign * window.
+		constexpr int kNoEvent = 0x7fffffff;
+		int key_u = kNoEvent, key_v = kNoEvent;
 		auto bisect = [&](bool flipping, int c0, float Ac, float Bc, float maxc) {
 			uint32_t lo = __float_as_uint(kx), hi = __float_as_uint(ky);
 			if (!flipping) hi = lo;
@@ -1261,10 +1314,42 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 				const bool same = cell(__uint_as_float(mid), Ac, Bc, maxc) == c0;
 				if (hi - lo > 1u) { if (same) lo = mid; else hi = mid; }
 			}
-			return flipping ? __uint_as_float(hi) : __builtin_inff();
+			return flipping ? dsign * window_of((int) VR_FMA(__uint_as_float(hi), Am, Bm_l)) : kNoEvent;
 		};
-		if (flips_u != 0ull) t_u = bisect(cu0 != cu1, cu0, Au, Bu, max_u);
-		if (flips_v != 0ull) t_v = bisect(cv0 != cv1, cv0, Av, Bv, max_v);
+		if (FLIPS && flips_u != 0ull) key_u = bisect(cu0 != cu1, cu0, Au, Bu, max_u);
+		if (FLIPS && flips_v != 0ull) key_v = bisect(cv0 != cv1, cv0, Av, Bv, max_v);
+		// the wave's distinct event keys in march order: lane i of `events` holds the i-th (kNoEvent beyond the last), so that the march
+		// compares the window it issues / consumes with ONE scalar and touches the lanes only where something happens
+		int events = kNoEvent;
+		bool events_ok = true;
+		if (FLIPS && has_flips) {
+			const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+			int last = (int) 0x80000000, count = 0;
+			#pragma nounroll
+			for (; count < 64; count++) {
+				int cand = key_u > last ? key_u : kNoEvent;
+				if (key_v > last && key_v < cand) cand = key_v;
+				#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1) { const int other = __shfl_xor(cand, d, 64); cand = other < cand ? other : cand; }
+				cand = (int) rfl((uint32_t) cand);
+				if (cand == kNoEvent) break;
+				events = lane_i == (uint32_t) count ? cand : events;
+				last = cand;
+			}
+			events_ok = count < 64;                                         // (more distinct events than lanes: cannot happen with <= 64 rows and columns per wave; marched per lane if it does)
+		}
+		// What a lane needs to know at its events, packed into ONE register for the march (the flips instantiation has to stay at 64
+		// VGPRs too): bits 0-11 / 12-23 its event keys + 1024 (0xfff: none; |key| <= 683 + 1 for edges up to 2048), bit 24 / 25 set =
+		// the step to its second column crosses a block edge, bit 28 / 29 set = the column index goes up.  The byte delta to the second
+		// column: +-16 (+-64 along v) inside a block, +-(block stride - 3 * 16) (- 3 * 64) across a block edge.
+		uint32_t flipinfo = 0x00ffffffu;
+		if (FLIPS && has_flips) {
+			const uint32_t pu = key_u == kNoEvent ? 0xfffu : (uint32_t) (key_u + 1024) & 0xfffu, pv = key_v == kNoEvent ? 0xfffu : (uint32_t) (key_v + 1024) & 0xfffu;
+			const bool up_u = cu1 > cu0, up_v = cv1 > cv0;
+			const bool cross_u = ((uint32_t) cu0 & 3u) == (up_u ? 3u : 0u), cross_v = ((uint32_t) cv0 & 3u) == (up_v ? 3u : 0u);
+			flipinfo = pu | (pv << 12) | (cross_u ? 1u << 24 : 0u) | (cross_v ? 1u << 25 : 0u) | (up_u ? 1u << 28 : 0u) | (up_v ? 1u << 29 : 0u);
+			events_ok = events_ok && __builtin_amdgcn_ballot_w64((key_u != kNoEvent && (key_u < -1023 || key_u > 1023)) || (key_v != kNoEvent && (key_v < -1023 || key_v > 1023))) == 0ull;
+		}
 
 		// -- the wave-uniform sample sequence, 64 samples at a time: lane j of `kvec` holds k of sample n + j, `lcvec` its (logical) cell
 		// along m, `wvec` the window that cell lies in.  The reference forms k by repeated fp32 additions k += step.  Inside one binade
@@ -1273,10 +1358,8 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		// fma(j, delta, k_n) with delta = fl(k_n + step) - k_n, no rounding (every term is a multiple of u inside the binade).  A batch that
 		// would cross a binade, a tie, or k <= 2^-102 is formed by the 64 sequential additions instead (lane j keeps the j-th sum): a handful
 		// of batches per ray.
-		const float inv_am = 1.0f / Am, span = 3.0f * __builtin_fabsf(inv_am) + 2.0f * step;       // k range one window can cover, with margin
-		const int dsign = (__float_as_uint(comp3<M>(dir)) >> 31) != 0u ? -1 : 1;     // from the kernel argument's bits: stays scalar
 		float kvec = 0.0f, knext = kx_l;
-		int lcvec = 0, wvec = 0;
+		int wvec = 0;
 		auto refill = [&]() {
 			const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // 0 .. 63
 			const float kbase = knext;
@@ -1294,10 +1377,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 				for (uint32_t j = 0; j < 64u; j++) { kvec = lane_i == j ? kc : kvec; kc = kc + step; }
 				knext = uni(kc);
 			}
-			lcvec = (int) VR_FMA(kvec, Am, Bm_l);                                            // truncation; may leave 0 .. Nm-1 past the exit
-			// window index = floor(cell / 3), also for the cells below 0 a ray reaches after its exit (biased by a multiple of 3; a cell index
-			// that must never stick to a window: the loops below end when the samples have moved on)
-			wvec = (int) (__umulhi((uint32_t) lcvec + 0x30000000u, 0xAAAAAAABu) >> 1) - 0x10000000;
+			wvec = window_of((int) VR_FMA(kvec, Am, Bm_l));                                  // (cell by truncation; may leave 0 .. Nm-1 past the exit)
 		};
 		refill();
 		int pos = 0;                                                        // next sample of the batch
@@ -1309,30 +1389,39 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		// ends of the copy (64 windows).
 		static_assert(2 * kColSlots + kColDepth + 4 <= 64, "kColPadBytes");
 		int guard = (dsign > 0 ? (int) nw - cur : cur + 1) + 2 * kColSlots;
-		uint64_t wa = s_base + (uint64_t) (uint32_t) cur * kColBlockBytes;      // address (before the lane offset) of the window being ISSUED
-		const uint64_t wa_step = (uint64_t) (int64_t) (dsign * (int) kColBlockBytes);
-		int wi = cur;                                                       // its index (only the flip logic needs it)
+		int woff = cur * (int) kColBlockBytes;                              // byte offset, inside a block's run of windows, of the window being ISSUED (may leave 0 .. nw * 256: see the guard)
 		auto march = [&](auto flips_tag) {
 			constexpr bool kFlips = decltype(flips_tag)::value;
-			// the k at which window W begins, predicted from the coordinate along m (any deterministic function of W is CORRECT — issue and
-			// consumption evaluate the same one; its accuracy only decides how often a window turns careful)
-			auto k_pred = [&](int W) { return ((float) (dsign > 0 ? 3 * W : 3 * W + 3) - Bm_l) * inv_am; };
+			// flips: `vo` follows the issue frontier — when it passes an event window, the lanes that flip there move on to their second column
+			uint32_t vo = voff0;
+			int issue_key = dsign * cur, issue_at = 0, issue_event = kFlips ? __builtin_amdgcn_readlane(events, 0) : kNoEvent;
+			int cons_at = 0, cons_event = issue_event;
 			auto issue = [&](u32x4 &dst) {
-				uint32_t vo = voff0;
 				if (kFlips) {
-					const float kp = k_pred(wi);
-					vo += (kp >= t_u ? d_u : 0u) + (kp >= t_v ? d_v : 0u);
-					wi += dsign;
+					while (issue_key > issue_event) {                        // (rare: a handful of events per ray)
+						ConstArgs q = dense_args();
+						const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
+						const uint32_t stride_u32 = col_windows(qdim_m) * kColBlockBytes, stride_v32 = ((qdim_u + 3u) >> 2) * stride_u32;      // < 2^28 (checked through du64 / dv64 for every lane that flips)
+						const uint32_t want = (uint32_t) (issue_event + 1024) & 0xfffu;
+						// integer arithmetic only (no lane masks: they would cost scalar registers in every window step): hit = all ones where the key matches
+						const uint32_t hit_u = (uint32_t) ((int) (((flipinfo ^ want) & 0xfffu) - 1u) >> 31), hit_v = (uint32_t) ((int) ((((flipinfo >> 12) ^ want) & 0xfffu) - 1u) >> 31);
+						const uint32_t mag_u = 16u + ((flipinfo >> 24) & 1u) * (stride_u32 - 64u), mag_v = 64u + ((flipinfo >> 25) & 1u) * (stride_v32 - 256u);
+						const uint32_t neg_u = ((flipinfo >> 28) & 1u) - 1u, neg_v = ((flipinfo >> 29) & 1u) - 1u;             // all ones = the column index goes down
+						vo += (((mag_u ^ neg_u) - neg_u) & hit_u) + (((mag_v ^ neg_v) - neg_v) & hit_v);                      // two's complement deltas: the 32-bit sum wraps back into range
+						issue_at++;
+						issue_event = __builtin_amdgcn_readlane(events, issue_at & 63);
+					}
+					issue_key++;
 				}
-#ifdef VR_BOUNDS_CHECK
-				(void) VR_BC_ADDRESS(a, wa + vo, 16u);
-#endif
-#ifdef VR_COL_EXP_NO_LOAD              // timing-only experiment: no gathers
-				dst = (u32x4) (vo & 0u);
+				const uint32_t lane_offset = vo + (uint32_t) woff;            // 2^30 - 2^28 - padding < lane_offset < 2^30 + 2^29: an unsigned 32-bit offset of the one scalar base
+#if defined(VR_BOUNDS_CHECK)           // debug build: the address is held against the copy (incl. its padding) and redirected if it leaves it
+				managed_load128(dst, VR_BC_ADDRESS(a, s_base + lane_offset, 16u));
+#elif defined(VR_COL_EXP_NO_LOAD)      // timing-only experiment: no gathers
+				dst = (u32x4) (lane_offset & 0u);
 #else
-				managed_load128_s(dst, vo, wa);
+				managed_load128_s(dst, lane_offset, s_base);
 #endif
-				wa += wa_step;
+				woff += dsign * (int) kColBlockBytes;
 			};
 			u32x4 slot[kColSlots];
 			slot[kColSlots - 1] = (u32x4) (0u);
@@ -1344,11 +1433,11 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 				pin(slot[c]); managed_wait<kColDepth>(); pin(slot[c]);
 				const u32x4 o = slot[c];
 				if (c == 0) live &= __builtin_amdgcn_fcmpf(rlane(kvec, pos), ky, kFcmpOLE);      // lazy exit test: once per rotation of the slots (and by every sample that composites)
-				bool careful = false;
+				bool careful = false;                                       // an event window: some lane changes its column somewhere inside
 				if (kFlips) {
-					// no lane's threshold in (min(k, kp), max(k + span, kp)]: the state a lane's column was issued for holds for every sample of the window
-					const float kf = rlane(kvec, pos), kp = k_pred(cur), lo = __builtin_fminf(kf, kp), hi = __builtin_fmaxf(kf + span, kp);
-					careful = __builtin_amdgcn_ballot_w64((t_u > lo && t_u <= hi) || (t_v > lo && t_v <= hi)) != 0ull;
+					const int key = issue_key - (kColDepth + 1);               // = dsign * cur: the issue frontier is kColDepth windows ahead and has just moved on
+					while (key > cons_event) { cons_at++; cons_event = __builtin_amdgcn_readlane(events, cons_at & 63); }
+					careful = key == cons_event;
 				}
 				const uint32_t all4 = (o.x | o.y | o.z | o.w) & a.skip_mask;
 				bool dense = careful;
@@ -1368,15 +1457,21 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 					const uint32_t first = (uint32_t) (cur * 3);
 					for (int batches = 0; batches < 5; batches++) {
 						const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wvec == cur));
-						for (int i = pos; i < pos + cnt; i++) {
-							k = rlane(kvec, i);
-							uint32_t w0, w1;
-							if (kFlips && careful) fetch_pair(VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), w0, w1);      // each lane's true column
-							else {
-								const uint32_t sub = (uint32_t) __builtin_amdgcn_readlane(lcvec, i) - first;
-								w0 = sub == 0u ? o.x : (sub == 1u ? o.y : o.z); w1 = sub == 0u ? o.y : (sub == 1u ? o.z : o.w);
+						if (kFlips && careful) {
+							// every sample from each lane's true column, explicitly (one exposed memory round trip per sample: a few windows per ray)
+							for (int i = pos; i < pos + cnt; i++) {
+								k = rlane(kvec, i);
+								uint64_t both;
+								fetch_at_managed(k, both);
+								pin(both); managed_wait<0>(); pin(both);               // (also the window gathers in flight: a careful window is rare)
+								sample((uint32_t) both, (uint32_t) (both >> 32));
 							}
-							sample(w0, w1);
+						} else {
+							for (int i = pos; i < pos + cnt; i++) {
+								k = rlane(kvec, i);
+								const uint32_t sub = rfl((uint32_t) (int) VR_FMA(k, Am, Bm_l)) - first;        // the sample's cell inside the window (the batch keeps only its window)
+								sample(sub == 0u ? o.x : (sub == 1u ? o.y : o.z), sub == 0u ? o.y : (sub == 1u ? o.z : o.w));
+							}
 						}
 						pos += cnt;
 						if (pos < 64) break;
@@ -1394,20 +1489,16 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 			managed_wait<0>();
 			static_for<0, kColSlots>([&](auto j) { pin(slot[j.value]); });
 		};
-		if (has_flips) march(std::true_type()); else march(std::false_type());
-	} else {
-		// per-lane march with explicit fetches (exact, unpipelined): the few waves that straddle two kx values, and forced testing
-		while (live != 0ull) {
-			uint32_t w0, w1;
-			fetch_pair(VR_FMA(k, A.x, B.x), VR_FMA(k, A.y, B.y), VR_FMA(k, A.z, B.z), w0, w1);
-			sample(w0, w1);
-			k += step;
-			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);
-		}
-	}
+		if (!events_ok || (has_flips && !FLIPS)) per_lane_march();
+		else march(std::integral_constant<bool, FLIPS>());
+	} else per_lane_march();
+	// what the final store needs is read off two vector registers the march keeps anyway (lane masks held across it would cost scalar
+	// registers): a lane has a segment iff its ky is positive (lanes without one were given -1), and is inside the buffer iff it has an index
+	uint32_t ky_bits = __float_as_uint(ky);
+	pin(ky_bits, out_index);
 	uint32_t rgba = 0;
-	if (hit) rgba = map_float_int(acc.x, 256) | (map_float_int(acc.y, 256) << 8) | (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
-	if (in_frame) out[out_index] = rgba;
+	if (__uint_as_float(ky_bits) > 0.0f) rgba = map_float_int(acc.x, 256) | (map_float_int(acc.y, 256) << 8) | (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
+	if (out_index != 0xffffffffu) ((ConstKernelArguments) dense_args())->out[out_index] = rgba;
 }
 
 // Which instantiation a frame runs: ONE selector, visited by the launcher and by the host's questions about the launch (does it read
@@ -1497,9 +1588,17 @@ hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const 
 		const dim3 grid(a.tiles_x * a.tiles_y), block(512);
 		const bool q8 = a.p.sampling == VR_SAMPLE_TRILINEAR_Q8;
 		auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, a, (const uint8_t *) bricked, tf, (uint32_t *) out); };
-		if (a.col_axis == 0u) { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 0>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 0>); }
-		else if (a.col_axis == 1u) { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 1>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 1>); }
-		else { if (q8) go(colmarch_kernel<VR_SAMPLE_TRILINEAR_Q8, 2>); else go(colmarch_kernel<VR_SAMPLE_TRILINEAR, 2>); }
+		// lateral direction components exactly 0: no lane can change its column — the kernel without the flip logic
+		const uint32_t m = a.col_axis;
+		const bool flips = a.p.view.direction[m == 0u ? 1 : 0] != 0.0f || a.p.view.direction[m == 2u ? 1 : 2] != 0.0f;
+		auto pick = [&](auto sampling, auto axis) {
+			constexpr int S = decltype(sampling)::value, AX = decltype(axis)::value;
+			if (flips) go(colmarch_kernel<S, AX, true>); else go(colmarch_kernel<S, AX, false>);
+		};
+		auto pick_axis = [&](auto sampling) {
+			if (m == 0u) pick(sampling, std::integral_constant<int, 0>()); else if (m == 1u) pick(sampling, std::integral_constant<int, 1>()); else pick(sampling, std::integral_constant<int, 2>());
+		};
+		if (q8) pick_axis(std::integral_constant<int, VR_SAMPLE_TRILINEAR_Q8>()); else pick_axis(std::integral_constant<int, VR_SAMPLE_TRILINEAR>());
 		return hipGetLastError();
 	}
 	return select_variant(args, bricked != nullptr, bpv, [&](auto sampling, auto voxel, auto addr, auto layout, bool reads_linear) {
@@ -1760,7 +1859,7 @@ template <int M>
 __global__ __launch_bounds__(256)
 void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 	typedef ColBuildCfg<M> S;
-	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
+	constexpr int U = M == 0 ? 1 : 0;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[S::rows * S::pitch];
 	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
 	const uint32_t nbu = (dim[U] + 3u) >> 2, nw = col_windows(dim[M]);
