@@ -432,7 +432,7 @@ def run_rank(a):
                 touched = recorded("tests/golden/vtouched.json", key)
                 alg_bytes = ((touched["mean_bytes"] if touched else n ** 3) + 4 * W * H) / world
             achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-            traffic = recorded("profiles/r03_traffic.json", f"{key}_n{world}") or recorded("profiles/r02_traffic.json", f"{key}_n{world}") or {}
+            traffic = recorded("profiles/r04_traffic.json", f"{key}_n{world}") or recorded("profiles/r03_traffic.json", f"{key}_n{world}") or recorded("profiles/r02_traffic.json", f"{key}_n{world}") or {}
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -34,14 +34,15 @@ def probe(vr, r, n, bpv, reps=3):
             out["prepare_error"] = str(e)
         wall = (time.perf_counter() - t0) * 1e3
         info = r.volume_info()
-        for k in range(7):
+        for k in range(vr.COPY_KINDS):
             if (info.copies >> k) & 1:
                 out["copies"].setdefault(vr.COPY_NAMES[k], []).append(round(info.build_ms[k], 3))
         out.setdefault("prepare_wall_ms", []).append(round(wall, 2))
     info = r.volume_info()
     elems = ((n + 7) // 8) ** 3 * 512
     sizes = {"quad_xy": elems * 4 * bpv, "quad_xz": elems * 4 * bpv, "quad_yz": elems * 4 * bpv, "run_z": ((n + 7) // 8) ** 3 * 2304,
-             "run_y": ((n + 7) // 8) ** 3 * 2304, "voxel": elems * bpv, "oct": elems * 8 * bpv}
+             "run_y": ((n + 7) // 8) ** 3 * 2304, "voxel": elems * bpv, "oct": elems * 8 * bpv,
+             "col_x": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_y": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_z": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256}
     out["rooflines"] = {}
     for name, ms in out["copies"].items():
         best = min(ms)

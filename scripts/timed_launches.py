@@ -14,12 +14,12 @@ rows = []
 for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "raymarch_kernel" in row["Kernel_Name"]:
+            if "march_kernel" in row["Kernel_Name"]:          # vr::raymarch_kernel<...> and vr::colmarch_kernel<...>
                 rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
 rows.sort()
 ms = [(e - s) / 1e6 for s, e, _ in rows]
 timed = ms[setup + warmup: setup + warmup + steps]
-names = [n.split("raymarch_kernel")[1].split(">")[0] + ">" for _, _, n in rows[setup + warmup: setup + warmup + steps]]
+names = [("col" if "colmarch" in n else "ray") + n.split("march_kernel")[1].split(">")[0] + ">" for _, _, n in rows[setup + warmup: setup + warmup + steps]]
 print(json.dumps({"command": f"rocprofv3 --kernel-trace --stats -- python bench.py --steps {steps} --warmup {warmup} --no-cpu-baseline --no-extras",
                   "raymarch_launches": len(ms), "first_launch_ms": round(ms[0], 3) if ms else None,
                   "timed_steps_ms": [round(x, 4) for x in timed], "timed_instantiations": names,

@@ -142,9 +142,24 @@ def test_no_instruction_touches_a_gather_in_flight(vr, tmp_path):
     checked = 0
     for name, lines in funcs.items():
         m = re.search(r"raymarch_kernelILi(\d)ELi1ELi0ELi(\d)E", name)
-        if not m or int(m.group(2)) not in (1, 2, 3, 4, 6):
+        column = re.search(r"colmarch_kernelILi\dELi\dELb[01]E", name) is not None      # the column march: one managed 16-byte gather per window
+        if not column and (not m or int(m.group(2)) not in (1, 2, 3, 4, 6)):
             continue
         checked += 1
+        # a register that appears in the function ONLY as the destination of loads is a sink (the column march warms the caches ahead of its
+        # event windows with loads whose result nobody reads): two such loads in flight into it cannot hurt anybody
+        elsewhere, load_dst = set(), set()
+        for ins in lines:
+            parts = ins.split(None, 1)
+            op, rest = parts[0], (parts[1] if len(parts) > 1 else "")
+            if re.match(r"(global|flat|buffer|scratch)_load", op):
+                load_dst |= _vgprs(rest.split(",")[0])
+            if re.match(r"(global|flat|buffer|scratch|ds)_(store|write|atomic)|v_cmp|v_readlane|v_readfirstlane", op):
+                elsewhere |= _vgprs(rest)                      # no vector destination: every operand is read
+            else:
+                elsewhere |= _vgprs(",".join(rest.split(",")[1:]))     # everything but the destination
+        sinks = load_dst - elsewhere
+        assert len(sinks) <= 1, (name, sinks)
         inflight, loads, waits = [], 0, 0
         for ins in lines:
             parts = ins.split(None, 1)
@@ -158,7 +173,7 @@ def test_no_instruction_touches_a_gather_in_flight(vr, tmp_path):
                         inflight = []
                     waits += 1
                 continue
-            regs = _vgprs(rest)
+            regs = _vgprs(rest) - sinks
             busy = set().union(*inflight) if inflight else set()
             assert not (regs & busy), f"{name}: `{ins}` names v{sorted(regs & busy)} while a load into it is in flight"
             if re.match(r"(global|flat|buffer|scratch)_load", op):
@@ -166,5 +181,5 @@ def test_no_instruction_touches_a_gather_in_flight(vr, tmp_path):
                 loads += 1
             elif re.match(r"(global|flat|buffer|scratch)_(store|atomic)", op):
                 inflight.append(set())                      # shares the counter; has no destination to protect
-        assert loads >= 20 and waits >= 10, (name, loads, waits)
-    assert checked >= 10, checked
+        assert (loads >= 20 or column and loads >= 8) and waits >= 10, (name, loads, waits)
+    assert checked >= 10 + 12, checked

@@ -732,7 +732,7 @@ def test_error_conventions(vr, golden):
     # policy switches and the profiling read-back: out-of-range values and premature calls are refused, the context keeps working
     tx, ty = C.c_uint32(7), C.c_uint32(7)
     assert L.vr_hip_read_tile_costs(r._ctx, None, 0, C.byref(tx), C.byref(ty)) == 5      # no frame with the cost map on yet
-    assert L.vr_hip_set_tile_scheduling(r._ctx, 3) == 1 and L.vr_hip_set_brick_plane(r._ctx, 8) == 1 and L.vr_hip_set_brick_plane(r._ctx, -2) == 1
+    assert L.vr_hip_set_tile_scheduling(r._ctx, 3) == 1 and L.vr_hip_set_brick_plane(r._ctx, 10) == 1 and L.vr_hip_set_brick_plane(r._ctx, -2) == 1
     assert L.vr_hip_set_tile_mapping(r._ctx, 16, 0, 0) == 1 and L.vr_hip_set_tile_mapping(r._ctx, 3, 0, 0) == 1 and L.vr_hip_set_tile_mapping(r._ctx, 0, 8, 0) == 1
     assert L.vr_hip_last_launch(r._ctx, None) == 1
     assert L.vr_hip_set_tile_scheduling(r._ctx, 2) == 0

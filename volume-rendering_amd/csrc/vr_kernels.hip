@@ -1396,18 +1396,22 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 			uint32_t vo = voff0;
 			int issue_key = dsign * cur, issue_at = 0, issue_event = kFlips ? __builtin_amdgcn_readlane(events, 0) : kNoEvent;
 			int cons_at = 0, cons_event = issue_event;
+			// byte delta to their second column for the lanes that flip in the event window `event` (0 for the others): integer arithmetic
+			// only (no lane masks: they would cost scalar registers in every window step)
+			auto event_delta = [&](int event) {
+				ConstArgs q = dense_args();
+				const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
+				const uint32_t stride_u32 = col_windows(qdim_m) * kColBlockBytes, stride_v32 = ((qdim_u + 3u) >> 2) * stride_u32;      // < 2^28 (checked through du64 / dv64 for every lane that flips)
+				const uint32_t want = (uint32_t) (event + 1024) & 0xfffu;
+				const uint32_t hit_u = (uint32_t) ((int) (((flipinfo ^ want) & 0xfffu) - 1u) >> 31), hit_v = (uint32_t) ((int) ((((flipinfo >> 12) ^ want) & 0xfffu) - 1u) >> 31);   // all ones where the key matches
+				const uint32_t mag_u = 16u + ((flipinfo >> 24) & 1u) * (stride_u32 - 64u), mag_v = 64u + ((flipinfo >> 25) & 1u) * (stride_v32 - 256u);
+				const uint32_t neg_u = ((flipinfo >> 28) & 1u) - 1u, neg_v = ((flipinfo >> 29) & 1u) - 1u;             // all ones = the column index goes down
+				return (((mag_u ^ neg_u) - neg_u) & hit_u) + (((mag_v ^ neg_v) - neg_v) & hit_v);                      // two's complement deltas: the 32-bit sums wrap back into range
+			};
 			auto issue = [&](u32x4 &dst) {
 				if (kFlips) {
 					while (issue_key > issue_event) {                        // (rare: a handful of events per ray)
-						ConstArgs q = dense_args();
-						const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
-						const uint32_t stride_u32 = col_windows(qdim_m) * kColBlockBytes, stride_v32 = ((qdim_u + 3u) >> 2) * stride_u32;      // < 2^28 (checked through du64 / dv64 for every lane that flips)
-						const uint32_t want = (uint32_t) (issue_event + 1024) & 0xfffu;
-						// integer arithmetic only (no lane masks: they would cost scalar registers in every window step): hit = all ones where the key matches
-						const uint32_t hit_u = (uint32_t) ((int) (((flipinfo ^ want) & 0xfffu) - 1u) >> 31), hit_v = (uint32_t) ((int) ((((flipinfo >> 12) ^ want) & 0xfffu) - 1u) >> 31);
-						const uint32_t mag_u = 16u + ((flipinfo >> 24) & 1u) * (stride_u32 - 64u), mag_v = 64u + ((flipinfo >> 25) & 1u) * (stride_v32 - 256u);
-						const uint32_t neg_u = ((flipinfo >> 28) & 1u) - 1u, neg_v = ((flipinfo >> 29) & 1u) - 1u;             // all ones = the column index goes down
-						vo += (((mag_u ^ neg_u) - neg_u) & hit_u) + (((mag_v ^ neg_v) - neg_v) & hit_v);                      // two's complement deltas: the 32-bit sum wraps back into range
+						vo += event_delta(issue_event);
 						issue_at++;
 						issue_event = __builtin_amdgcn_readlane(events, issue_at & 63);
 					}
