@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""The timed ray-march launches of a `rocprofv3 --kernel-trace -- python bench.py ...` run, from the kernel trace: bench.py renders 32
-set-up frames (4 per view), W warm-up steps, then the K timed steps; prints a JSON object with their durations in start order.
-usage: timed_launches.py <dir with *kernel_trace.csv> <warmup> <steps> [setup frames = 32]"""
+"""The timed ray-march launches of a `rocprofv3 --kernel-trace -- python bench.py ...` run, from the kernel trace: bench.py renders 8
+set-up frames (one per view), W warm-up steps, then the K timed steps; prints a JSON object with their durations in start order.
+usage: timed_launches.py <dir with *kernel_trace.csv> <warmup> <steps> [setup frames = 8]"""
 import csv
 import glob
 import json
@@ -9,7 +9,7 @@ import os
 import sys
 
 root, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-setup = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+setup = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 rows = []
 for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     with open(f) as fh:
@@ -24,7 +24,6 @@ print(json.dumps({"command": f"rocprofv3 --kernel-trace --stats -- python bench.
                   "raymarch_launches": len(ms), "first_launch_ms": round(ms[0], 3) if ms else None,
                   "timed_steps_ms": [round(x, 4) for x in timed], "timed_instantiations": names,
                   "timed_mean_ms": round(sum(timed) / max(1, len(timed)), 4), "timed_max_ms": round(max(timed), 4) if timed else None,
-                  "note": f"launches {setup + warmup + 1}..{setup + warmup + steps} in start order are the timed steps ({setup} set-up frames, 4 per view, and {warmup} warm-up "
+                  "note": f"launches {setup + warmup + 1}..{setup + warmup + steps} in start order are the timed steps ({setup} set-up frames, one per view, and {warmup} warm-up "
                           "frames precede them); the summary csv averages ALL launches of an instantiation, including the very first one on each brick copy "
-                          "(first touch of 4 GiB: tens of ms) and the frames of the oblique orthogonal view that run on a single run copy before its per-tile "
-                          "choice exists - bench.py's set-up pass keeps those out of its timed region"}, indent=1))
+                          "(first touch of 4-5 GiB: several ms) - bench.py's set-up pass keeps those out of its timed region"}, indent=1))

@@ -186,7 +186,15 @@ enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ =
                   kCopyKinds = 10 };
 static_assert(kCopyKinds == VR_COPY_KINDS, "include/vr_hip.h VR_COPY_KINDS");
 // column windows (kLayoutColumn): lateral axes (u, v) of march axis m are the two other axes in increasing order
-constexpr uint32_t kColCells = 3, kColWindowBytes = 16, kColBlockBytes = 256;       // cells per window; 4x4 columns x 16 bytes
+// A lateral block is kColEdge x kColEdge cell columns: its windows are kColBlockBytes each and follow each other along m.  4 x 4 columns
+// = what one wave's 8 x 8 pixels cover at the reference's zoom, 256 bytes per window.  Measured against 8 x 8 columns (1 KiB per window
+// of a block, -DVR_COL_EDGE_LOG2=3; full march, the three axis-aligned poses): 1.79 / 1.84 / 2.30 ms against 1.82 / 1.88 / 2.59 ms.
+#ifndef VR_COL_EDGE_LOG2
+#define VR_COL_EDGE_LOG2 2
+#endif
+constexpr uint32_t kColEdgeLog2 = VR_COL_EDGE_LOG2, kColEdge = 1u << kColEdgeLog2, kColEdgeMask = kColEdge - 1u;
+constexpr uint32_t kColCells = 3, kColWindowBytes = 16, kColRowBytes = kColEdge * kColWindowBytes, kColBlockBytes = kColEdge * kColRowBytes;       // cells per window; edge x edge columns x 16 bytes
+__host__ __device__ constexpr uint32_t col_blocks(uint32_t n) { return (n + kColEdgeMask) >> kColEdgeLog2; }
 __host__ __device__ constexpr uint32_t col_axis_u(uint32_t m) { return m == 0u ? 1u : 0u; }
 __host__ __device__ constexpr uint32_t col_axis_v(uint32_t m) { return m == 2u ? 1u : 2u; }
 __host__ __device__ inline uint32_t col_windows(uint32_t nm) { return (nm + kColCells - 1u) / kColCells; }
@@ -195,7 +203,7 @@ __host__ __device__ inline uint32_t col_windows(uint32_t nm) { return (nm + kCol
 // this much zeroed padding (64 windows).  The kernel bounds its window count by the windows left in march direction + kColSlots + 2 (colmarch_kernel).
 constexpr uint32_t kColPadBytes = 64u * kColBlockBytes;
 inline uint64_t col_copy_bytes(const uint32_t dim[3], uint32_t m) {      // without the padding
-	return (uint64_t) ((dim[col_axis_u(m)] + 3u) / 4u) * ((dim[col_axis_v(m)] + 3u) / 4u) * col_windows(dim[m]) * kColBlockBytes;
+	return (uint64_t) col_blocks(dim[col_axis_u(m)]) * col_blocks(dim[col_axis_v(m)]) * col_windows(dim[m]) * kColBlockBytes;
 }
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {

@@ -1166,10 +1166,10 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	const float Bm = comp3<M>(B), Bu = comp3<U>(B), Bv = comp3<V>(B);
 	const uint32_t dim_u = U == 0 ? a.dim_x : a.dim_y, dim_m = M == 0 ? a.dim_x : (M == 1 ? a.dim_y : a.dim_z);
 	const float max_u = U == 0 ? a.max_x : a.max_y, max_v = V == 1 ? a.max_y : a.max_z;
-	const uint32_t nbu = (dim_u + 3u) >> 2, nw = col_windows(dim_m);
+	const uint32_t nbu = col_blocks(dim_u), nw = col_windows(dim_m);
 	const uint64_t stride_u = (uint64_t) nw * kColBlockBytes, stride_v = (uint64_t) nbu * stride_u;       // bytes between lateral blocks
-	auto f_u = [&](int c) { return (uint64_t) ((uint32_t) c >> 2) * stride_u + ((uint32_t) c & 3u) * 16u; };
-	auto f_v = [&](int c) { return (uint64_t) ((uint32_t) c >> 2) * stride_v + ((uint32_t) c & 3u) * 64u; };
+	auto f_u = [&](int c) { return (uint64_t) ((uint32_t) c >> kColEdgeLog2) * stride_u + ((uint32_t) c & kColEdgeMask) * kColWindowBytes; };
+	auto f_v = [&](int c) { return (uint64_t) ((uint32_t) c >> kColEdgeLog2) * stride_v + ((uint32_t) c & kColEdgeMask) * kColRowBytes; };
 
 	f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
 	uint64_t live = alive_mask;
@@ -1188,8 +1188,8 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		const uint32_t iu = (uint32_t) (U == 0 ? ix : iy), iv = (uint32_t) (V == 1 ? iy : iz), im = (uint32_t) (M == 0 ? ix : (M == 1 ? iy : iz));
 		const uint32_t wq = __umulhi(im, 0xAAAAAAABu) >> 1, sub = im - wq * 3u;
 		const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
-		const uint32_t block = ((iv >> 2) * ((qdim_u + 3u) >> 2) + (iu >> 2)) * col_windows(qdim_m) + wq;
-		const uint8_t *p = ((ConstKernelArguments) q)->copy + (((uint64_t) block << 8) + (iv & 3u) * 64u + (iu & 3u) * 16u + sub * 4u);
+		const uint32_t block = ((iv >> kColEdgeLog2) * col_blocks(qdim_u) + (iu >> kColEdgeLog2)) * col_windows(qdim_m) + wq;
+		const uint8_t *p = ((ConstKernelArguments) q)->copy + ((uint64_t) block * kColBlockBytes + (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + sub * 4u);
 		return VR_BC_POINTER(a, const uint8_t *, p, 8u);
 	};
 	auto fetch_pair = [&](ConstArgs q, float xb, float yb, float zb, uint32_t &w0, uint32_t &w1) {
@@ -1346,7 +1346,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		if (FLIPS && has_flips) {
 			const uint32_t pu = key_u == kNoEvent ? 0xfffu : (uint32_t) (key_u + 1024) & 0xfffu, pv = key_v == kNoEvent ? 0xfffu : (uint32_t) (key_v + 1024) & 0xfffu;
 			const bool up_u = cu1 > cu0, up_v = cv1 > cv0;
-			const bool cross_u = ((uint32_t) cu0 & 3u) == (up_u ? 3u : 0u), cross_v = ((uint32_t) cv0 & 3u) == (up_v ? 3u : 0u);
+			const bool cross_u = ((uint32_t) cu0 & kColEdgeMask) == (up_u ? kColEdgeMask : 0u), cross_v = ((uint32_t) cv0 & kColEdgeMask) == (up_v ? kColEdgeMask : 0u);
 			flipinfo = pu | (pv << 12) | (cross_u ? 1u << 24 : 0u) | (cross_v ? 1u << 25 : 0u) | (up_u ? 1u << 28 : 0u) | (up_v ? 1u << 29 : 0u);
 			events_ok = events_ok && __builtin_amdgcn_ballot_w64((key_u != kNoEvent && (key_u < -1023 || key_u > 1023)) || (key_v != kNoEvent && (key_v < -1023 || key_v > 1023))) == 0ull;
 		}
@@ -1401,10 +1401,10 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 			auto event_delta = [&](int event) {
 				ConstArgs q = dense_args();
 				const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
-				const uint32_t stride_u32 = col_windows(qdim_m) * kColBlockBytes, stride_v32 = ((qdim_u + 3u) >> 2) * stride_u32;      // < 2^28 (checked through du64 / dv64 for every lane that flips)
+				const uint32_t stride_u32 = col_windows(qdim_m) * kColBlockBytes, stride_v32 = col_blocks(qdim_u) * stride_u32;      // < 2^28 (checked through du64 / dv64 for every lane that flips)
 				const uint32_t want = (uint32_t) (event + 1024) & 0xfffu;
 				const uint32_t hit_u = (uint32_t) ((int) (((flipinfo ^ want) & 0xfffu) - 1u) >> 31), hit_v = (uint32_t) ((int) ((((flipinfo >> 12) ^ want) & 0xfffu) - 1u) >> 31);   // all ones where the key matches
-				const uint32_t mag_u = 16u + ((flipinfo >> 24) & 1u) * (stride_u32 - 64u), mag_v = 64u + ((flipinfo >> 25) & 1u) * (stride_v32 - 256u);
+				const uint32_t mag_u = kColWindowBytes + ((flipinfo >> 24) & 1u) * (stride_u32 - kColRowBytes), mag_v = kColRowBytes + ((flipinfo >> 25) & 1u) * (stride_v32 - kColBlockBytes);
 				const uint32_t neg_u = ((flipinfo >> 28) & 1u) - 1u, neg_v = ((flipinfo >> 29) & 1u) - 1u;             // all ones = the column index goes down
 				return (((mag_u ^ neg_u) - neg_u) & hit_u) + (((mag_v ^ neg_v) - neg_v) & hit_v);                      // two's complement deltas: the 32-bit sums wrap back into range
 			};
@@ -1852,8 +1852,8 @@ hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_
 // axis itself for m = x, hence the two tile shapes — then writes the windows with 16-byte stores in copy order: thread t -> (block, window,
 // column), 256 contiguous bytes per (block, window), a block's windows back to back.  Bound: HBM, bytes = linear + copy.
 template <int M> struct ColBuildCfg {
-	static constexpr uint32_t nbu = M == 0 ? 4u : 32u, nwin = M == 0 ? 85u : 8u;
-	static constexpr uint32_t tu = 4u * nbu + 1u, tv = 5u, te = kColCells * nwin + 1u;
+	static constexpr uint32_t nbu = (M == 0 ? 16u : 128u) / kColEdge, nwin = M == 0 ? 85u : 8u;        // 16 / 128 columns along u per workgroup
+	static constexpr uint32_t tu = kColEdge * nbu + 1u, tv = kColEdge + 1u, te = kColCells * nwin + 1u;
 	static constexpr uint32_t tx = M == 0 ? te : tu;                           // tile extent along x (the contiguous axis of the linear array)
 	static constexpr uint32_t pitch = (tx + 3u) / 4u * 4u + 4u;               // bytes per staged x-row (multiple of 4, rows shifted over the banks)
 	static constexpr uint32_t rows = M == 0 ? tu * tv : tv * te;              // staged rows
@@ -1866,9 +1866,9 @@ void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ ou
 	constexpr int U = M == 0 ? 1 : 0;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[S::rows * S::pitch];
 	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
-	const uint32_t nbu = (dim[U] + 3u) >> 2, nw = col_windows(dim[M]);
+	const uint32_t nbu = col_blocks(dim[U]), nw = col_windows(dim[M]);
 	const uint32_t bu0 = blockIdx.x * S::nbu, bv = blockIdx.y, w0 = blockIdx.z * S::nwin;
-	const uint32_t u0 = bu0 * 4u, v0 = bv * 4u, e0 = w0 * kColCells;
+	const uint32_t u0 = bu0 * kColEdge, v0 = bv * kColEdge, e0 = w0 * kColCells;
 	const uint32_t t = threadIdx.x;
 	// row r of the tile: m = y, z: r = dv * te + de holds u = u0 ..; m = x: r = dv * tu + du holds e = e0 ..  (x runs along the row either way)
 	auto row_of = [&](uint32_t du, uint32_t dv, uint32_t de) { return M == 0 ? dv * S::tu + du : dv * S::te + de; };
@@ -1897,9 +1897,10 @@ void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ ou
 	}
 	__syncthreads();
 	const uint32_t blocks_here = nbu - bu0 < S::nbu ? nbu - bu0 : S::nbu, wins_here = nw - w0 < S::nwin ? nw - w0 : S::nwin;
-	for (uint32_t i = t; i < blocks_here * wins_here * 16u; i += 256u) {
-		const uint32_t col = i & 15u, bw = i >> 4, w = bw % wins_here, b = bw / wins_here;
-		const uint32_t du = b * 4u + (col & 3u), dv = col >> 2;
+	constexpr uint32_t kCols = kColEdge * kColEdge;
+	for (uint32_t i = t; i < blocks_here * wins_here * kCols; i += 256u) {
+		const uint32_t col = i & (kCols - 1u), bw = i / kCols, w = bw % wins_here, b = bw / wins_here;
+		const uint32_t du = b * kColEdge + (col & kColEdgeMask), dv = col >> kColEdgeLog2;
 		uint32_t word[4];
 		#pragma unroll
 		for (uint32_t j = 0; j < 4u; j++) {
@@ -1909,13 +1910,13 @@ void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ ou
 			const uint32_t de = e - e0;
 			word[j] = at(du, dv, de) | (at(du + 1u, dv, de) << 8) | (at(du, dv + 1u, de) << 16) | (at(du + 1u, dv + 1u, de) << 24);
 		}
-		out[((uint64_t) ((uint64_t) bv * nbu + bu0 + b) * nw + w0 + w) * 16u + col] = make_uint4(word[0], word[1], word[2], word[3]);
+		out[((uint64_t) ((uint64_t) bv * nbu + bu0 + b) * nw + w0 + w) * kCols + col] = make_uint4(word[0], word[1], word[2], word[3]);
 	}
 }
 
 hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
 	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
-	const uint32_t nbu = (dim[col_axis_u(axis)] + 3u) / 4u, nbv = (dim[col_axis_v(axis)] + 3u) / 4u, nw = col_windows(dim[axis]);
+	const uint32_t nbu = col_blocks(dim[col_axis_u(axis)]), nbv = col_blocks(dim[col_axis_v(axis)]), nw = col_windows(dim[axis]);
 	auto grid = [&](uint32_t per_u, uint32_t per_w) { return dim3((nbu + per_u - 1u) / per_u, nbv, (nw + per_w - 1u) / per_w); };
 	if (axis == 0) hipLaunchKernelGGL(column_build_kernel<0>, grid(ColBuildCfg<0>::nbu, ColBuildCfg<0>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
 	else if (axis == 1) hipLaunchKernelGGL(column_build_kernel<1>, grid(ColBuildCfg<1>::nbu, ColBuildCfg<1>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
