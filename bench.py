@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--mode", choices=("nooptims", "default", "ertonly"), default="nooptims")
     ap.add_argument("--sampling", choices=("trilinear", "nearest"), default="trilinear")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per interleaved band (0 = automatic)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=(0, 1, 2, 3),
+                    help="frames a rank keeps in flight: 1 = interactive (every frame is finished before the next starts: ms_per_step IS the frame latency), "
+                         "3 = throughput (default for N >= 2, each on a stream of its own), 0 = automatic (N = 1: two on one stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--extras", default="modes,first,host,scale,configs,linear,multi,builders",
@@ -288,10 +291,12 @@ def run_rank(a):
         # kernel's own duration.
         many_streams = world >= 2 or os.environ.get("VR_BENCH_TWO_STREAMS") == "1"     # the env switch rehearses the pipeline on one GPU
         slot_streams = [render_stream] + [torch.cuda.Stream(device) for _ in range(2)] if many_streams else [render_stream, render_stream]
+        if a.frames_in_flight:
+            slot_streams = slot_streams[:a.frames_in_flight]
 
     import contextlib
     if a.dry_run:
-        slot_streams = [None] * (3 if world >= 2 else 2)
+        slot_streams = [None] * (a.frames_in_flight or (3 if world >= 2 else 2))
     slots = len(slot_streams)
 
     def on_slot(slot):
@@ -375,24 +380,37 @@ def run_rank(a):
         torch.cuda.synchronize()
         return "ok" if torch.equal(final[i % slots], whole) else "MISMATCH"
 
+    def latency_region(frames=16):
+        """north_star's "ms/frame" for an interactive viewer: ONE frame at a time through the same N-rank path (render, gather,
+        de-interleave), finished before the next one starts — no frame hides behind another.  Outside the timed region."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            step(i)
+            fence()
+        return (time.perf_counter() - t0) / frames
+
     if stream_ctx is not None:
         with stream_ctx:
             elapsed = timed_region()
             tm = r.timing()
             frame_check = check_frame()
+            latency = latency_region()
     else:
         elapsed = timed_region()
         tm = None
         frame_check = check_frame()
+        latency = latency_region()
 
     per_rank_kernel_ms = [tm.kernel_ms_sum / max(1, tm.launches)] if tm is not None else [0.0]
     kernel_ms_max = float(tm.kernel_ms_max) if tm is not None else 0.0       # the longest single launch (Profiler.cpp:69-72 keeps sum and max)
     if distributed:
-        t = torch.tensor([elapsed, per_rank_kernel_ms[0], kernel_ms_max], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, per_rank_kernel_ms[0], kernel_ms_max, latency], dtype=torch.float64, device=device)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                   # SURVEY §8e: scaling is set by load balance — report every rank's kernel time
         per_rank_kernel_ms = [float(e[1]) for e in every]
         elapsed, kernel_ms, kernel_ms_max = max(float(e[0]) for e in every), max(per_rank_kernel_ms), max(float(e[2]) for e in every)
+        latency = max(float(e[3]) for e in every)
     else:
         kernel_ms = per_rank_kernel_ms[0]
 
@@ -402,13 +420,17 @@ def run_rank(a):
         mrays = W * H / (elapsed / a.steps) / 1e6
         partition = (f"{world} rank(s) x interleaved {band_rows}-row bands, "
                      f"{'gloo' if a.dry_run else 'RCCL'} gather to rank 0, {slots} frames in flight"
-                     f"{' rendered concurrently (one stream per slot)' if slot_streams[0] is not slot_streams[1] else ''}") if distributed else "single GPU, whole frame"
+                     f"{' rendered concurrently (one stream per slot)' if slots > 1 and slot_streams[0] is not slot_streams[1] else ''}") if distributed else "single GPU, whole frame"
         out = {
             "metric": f"Mrays/s (W*H / t_frame), {n}^3 volume @ {W}x{H} viewport" if (n, W, H) != (1024, 2048, 2048) else
                       "Mrays/s (W*H / t_frame), 1024^3 volume @ 2048^2 viewport", "value": round(mrays, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "frame_check": frame_check,
+            # north_star asks for "Mrays/s + ms/frame": `value` / `ms_per_step` are THROUGHPUT with `frames_in_flight` frames of a rank in
+            # flight (a renderer that feeds an encoder); `ms_per_frame_latency` is ONE frame through the same path with nothing else in
+            # flight (an interactive viewer), measured over 16 synchronous frames after the timed region.  At N = 1 both are the kernel.
+            "frames_in_flight": slots, "ms_per_frame_latency": round(latency * 1e3, 4), "Mrays_per_s_latency": round(W * H / latency / 1e6, 2) if latency > 0 else None,
         }
         if frame_check != "ok":
             rc = 4
@@ -441,17 +463,18 @@ def run_rank(a):
                 "traffic_GBs": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9, 1) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
                 # what the kernel actually moves against the HBM peak (the copies it reads are 4 - 4.5 bytes per voxel and fetched 1 - 2.4 times)
                 "traffic_frac_of_peak": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
-                "kernel": "vr::raymarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
+                "kernel": "vr::raymarch_kernel + vr::colmarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernel_instantiations": "raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks (aligned views along a volume axis), 2 / 3 run bricks along z / y "
-                                         "(every other TRILINEAR view), 6 both run copies chosen per block of tiles (orthogonal views that are not along an axis, from their fifth frame on), "
-                                         "4 voxel bricks (NEAREST); kernel_ms = hipEvent mean over ALL timed launches",
+                "kernel_instantiations": "the frame's ONE launch is colmarch_kernel<sampling, axis, flips> for full-march frames of orthogonal views along a volume axis "
+                                         "(column windows: three of the eight benchmark views), else raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks, 2 / 3 run bricks along z / y, "
+                                         "6 both run copies chosen per block of tiles (orthogonal views that are not along an axis), 4 voxel bricks (NEAREST); "
+                                         "kernel_ms = hipEvent mean over ALL timed launches (the views cycle)",
                 "per_rank_kernel_ms": [round(x, 4) for x in per_rank_kernel_ms],
                 "kernel_ms_note": ("N >= 2: the three frames a rank has in flight render concurrently (one stream per slot), so kernel_ms is the duration of a "
                                    "launch that shares the chip with its neighbour — longer than the kernel alone; `value` (frames per second over all ranks) is the figure "
                                    "that counts, `scale_model` at N = 1 holds the per-rank kernel times without overlap") if slot_streams[0] is not slot_streams[1] else None,
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
-                "note": "full march is gather / VALU-issue bound, not HBM bound (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "
+                "note": "the column-window views are HBM bound (5.7 GB of copy per frame at 4.3 TB/s), the others gather / VALU-issue bound (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "
                         "exact per-wave shortcuts (transparent samples, rays whose accumulated alpha is exactly 1) skip arithmetic only"}
             out["minmax_feeder"] = {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
                                     "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),

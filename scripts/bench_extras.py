@@ -164,7 +164,11 @@ def host_buffer_leg(vr, r, scene, views, sampling):
 def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ranks=(2, 4, 8), modes=("nooptims", "default")):
     """What ONE GPU can say about N: every rank's band set (the same interleaved bands the N-rank run uses) rendered alone, per
     view; predicted efficiency = mean over views of t_1 / (N * max_r t_r) — load balance only, no gather, no host overhead."""
-    out = {"what": "each rank's bands rendered alone on this GPU (kernel ms, hipEvents); efficiency = mean_v t1(v) / (N * max_r t_r(v)); "
+    out = {"simulation": "ONE GPU renders what each of N ranks would (no second device, no gather): a prediction, not a measurement at N",
+           "which_number_is_ms_per_frame": "latency_ms_per_frame = one frame, nothing else in flight (interactive viewer: north_star's ms/frame); "
+                                           "throughput_ms_per_frame_3_in_flight = three frames of a rank in flight (+2 frames of latency); the older keys "
+                                           "predicted_ms_per_frame / pipelined_ms_per_frame hold the same two figures",
+           "what": "each rank's bands rendered alone on this GPU (kernel ms, hipEvents); efficiency = mean_v t1(v) / (N * max_r t_r(v)); "
                    "load balance only — the gather (16 MiB / N per rank over xGMI) and host overhead are not in it.  pipelined_*: rank 0's bands of "
                    "consecutive frames rendered CONCURRENTLY on three streams (three frames in flight), as the N-rank run does (wall ms per frame over 48 frames): a rank's share "
                    "of a frame fills the chip only briefly, two of them side by side keep it busy"}
@@ -195,7 +199,23 @@ def scale_model(vr, dmod, r, scene, views, W, H, sampling, buf, stream, sync, ra
                     r.render_volume_device(ps0[i % len(ps0)], bufs3[i % 3].data_ptr(), three[i % 3].cuda_stream)
                 torch.cuda.synchronize()
                 piped = (time.perf_counter() - t0) / 48 * 1e3
+            # the LATENCY of one frame at N ranks = the slowest rank's band set rendered alone (what an interactive viewer waits for, before
+            # the gather); finer bands even the mix of long and short rays a rank gets: 64- and 32-row bands beside the default
+            finer = {}
+            for rows in (64, 32):
+                if rows >= band_rows or H // rows < 2 * n:
+                    continue
+                worst = [0.0] * len(views)
+                for rank in range(n):
+                    sp = dmod.FrameSplit(W, H, n, rank, rows)
+                    per_view, _, _ = time_views(r, [sp.apply(scene.frame_params(v, sampling)) for v in views], buf, stream, sync, reps=2)
+                    worst = [max(a_, b_) for a_, b_ in zip(worst, per_view)]
+                finer[str(rows)] = round(sum(worst) / len(worst), 4)
             res[f"n{n}"] = {"band_rows": band_rows, "per_rank_kernel_ms": [round(x, 4) for x in per_rank],
+                            "latency_ms_per_frame": round(sum(max(per_rank_view[k][v] for k in range(n)) for v in range(len(views))) / len(views), 4),
+                            "latency_efficiency": round(sum(eff) / len(eff), 4),
+                            "latency_ms_per_frame_by_band_rows": finer,
+                            "throughput_ms_per_frame_3_in_flight": round(piped, 4), "throughput_efficiency_3_in_flight": round(sum(t1) / len(t1) / (n * piped), 4),
                             "pipelined_ms_per_frame": round(piped, 4), "predicted_efficiency_pipelined": round(sum(t1) / len(t1) / (n * piped), 4),
                             "max_over_mean": round(max(per_rank) / (sum(per_rank) / n), 4),
                             "predicted_efficiency": round(sum(eff) / len(eff), 4),

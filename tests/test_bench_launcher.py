@@ -30,6 +30,16 @@ def test_bench_launches_its_own_ranks(gpus, viewport, band):
     assert out["n_gpus"] == gpus and out["steps"] == 4 and out["warmup"] == 2
     assert out["dry_run"] is True and out["frame_check"] == "ok"
     assert out["scaling"] == "strong" and out["higher_is_better"] is True
+    # north_star's "Mrays/s + ms/frame": throughput with the frames of a rank in flight AND the latency of one synchronous frame
+    assert out["frames_in_flight"] == 3 and out["ms_per_frame_latency"] > 0
+
+
+def test_frames_in_flight_is_a_parameter():
+    """--frames-in-flight 1 = the interactive configuration: every frame is finished before the next starts."""
+    rc, lines, err = _run(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1", "--viewport", "96", "--frames-in-flight", "1"])
+    assert rc == 0, err[-2000:]
+    out = json.loads(lines[0])
+    assert out["frames_in_flight"] == 1 and out["frame_check"] == "ok" and "1 frames in flight" in out["config"]["partition"]
 
 
 def test_bench_rejects_mismatched_world():
