@@ -962,6 +962,9 @@ int vr_hip_set_transfer_fn(vr_ctx *c, const float *tf, const uint32_t *esl) {
 		zero++;
 	c->tf_zero_below = (float) zero;
 	c->tf_set = true;
+	// tile orders recorded under the old transfer function describe other ray lengths (placement only; nothing is in flight here: drained above)
+	for (auto &e : c->map_cache) { e.dual_state = 0; e.order_tiles = 0; }
+	for (auto &e : c->order_cache) { e.has_last = false; e.repeats = 0; for (auto &sl : e.slot) sl.valid = false; }
 	return VR_OK;
 }
 

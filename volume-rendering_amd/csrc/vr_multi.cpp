@@ -89,7 +89,8 @@ struct vr_multi {
 	void *frame0 = nullptr;                         // device 0: assembled frame of the host-buffer entry point
 	void *check = nullptr;                          // device 0: self-check scratch (one band slice) + mismatch counter
 	uint32_t *check_count = nullptr;
-	bool check_next = false;                        // self-check the next frame (first frame after set_window on distinct devices)
+	int check_left = 0;                             // self-check this many more frames: the first kFrames + 1 after set_window on distinct devices, i.e. frame 0
+	                                                // and the first REUSE of every pipeline slot (frame 0 alone says nothing about the retire ordering)
 	uint32_t width = 0, height = 0, band_rows = 0, per_rank = 0, local_rows = 0;
 	Transport transport = kSingle;
 	bool distinct = true;
@@ -332,8 +333,9 @@ int vr_hip_multi_set_window(vr_multi *m, uint32_t w, uint32_t h) {
 		}
 	}
 	const char *sc = getenv("VR_MULTI_SELFCHECK");
-	m->check_next = m->n > 1 && (sc ? atoi(sc) != 0 : m->distinct);
-	if (m->check_next) {
+	const bool checking = m->n > 1 && (sc ? atoi(sc) != 0 : m->distinct);
+	m->check_left = checking ? (sc && atoi(sc) > 1 ? atoi(sc) : kFrames + 1) : 0;          // VR_MULTI_SELFCHECK=<n> (n > 1): that many frames
+	if (checking && m->check == nullptr) {
 		VRM_TRY(m, hipSetDevice(m->dev[0]));
 		VRM_TRY(m, hipMalloc(&m->check, slice));
 		VRM_TRY(m, hipMalloc((void **) &m->check_count, sizeof(uint32_t)));
@@ -446,9 +448,9 @@ int vr_hip_multi_render_device_async(vr_multi *m, const vr_params *p, void *dev_
 	if (consumer_stream) VRM_TRY_FRAME(m, hipStreamWaitEvent((hipStream_t) consumer_stream, m->t1[slot], 0));
 	m->in_flight[slot] = true;
 	m->frames++;
-	if (m->check_next && m->n > 1) {
-		// First frame on this window: device 0 renders every other rank's bands itself and compares them with what arrived.
-		m->check_next = false;
+	if (m->check_left > 0 && m->n > 1) {
+		// One of the first frames on this window: device 0 renders every other rank's bands itself and compares them with what arrived.
+		m->check_left--;
 		VRM_TRY_FRAME(m, hipSetDevice(m->dev[0]));
 		VRM_TRY_FRAME(m, hipMemsetAsync(m->check_count, 0, sizeof(uint32_t), stream[0]));
 		for (int r = 1; r < m->n; r++) {

@@ -242,7 +242,8 @@ class MultiRenderer:
         self._check(self._L.vr_hip_multi_render_device(self._m, C.byref(params), C.c_void_p(dev_ptr)), "render_volume_device")
 
     def render_volume_device_async(self, params, dev_ptr, consumer_stream=None):
-        """Queues a frame (two in flight); `consumer_stream` (raw hipStream_t on devices[0]) waits for the assembled frame."""
+        """Queues a frame (up to THREE in flight: kFrames in vr_multi.cpp; frames in flight must not share `dev_ptr`); `consumer_stream`
+        (raw hipStream_t on devices[0]) waits for the assembled frame."""
         self._check(self._L.vr_hip_multi_render_device_async(self._m, C.byref(params), C.c_void_p(dev_ptr),
                                                              C.c_void_p(consumer_stream) if consumer_stream else None), "render_volume_device_async")
 
