@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call i: the column test with a build variant (VR_HIP_LIB), then its timing on views 0,2,3.  usage: gpu_r04_i.sh <variant>...
+# A/B of build variants: the column-march parity test with each variant (VR_HIP_LIB), then its kernel times on the three axis-aligned poses.  usage: gpu_variant_probe.sh <variant>...
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04_i; mkdir -p $O
 for lib in "$@"; do
