@@ -283,8 +283,11 @@ uint32_t vr_hip_multi_default_band_rows(uint32_t height, uint32_t n);
 #define VR_COPY_COL_X    (1u << 7)   /* column windows along x / y / z (1-byte voxels, edges <= 2048): per cell column, four consecutive quad */
 #define VR_COPY_COL_Y    (1u << 8)   /* elements along the axis in ONE aligned 16-byte word; what TRILINEAR reads for full-march frames of */
 #define VR_COPY_COL_Z    (1u << 9)   /* ORTHOGONAL views along that axis: one gather and one transparency test per ~3 samples (vr_device.h) */
-#define VR_COPY_ALL      0x3ffu
-#define VR_COPY_KINDS    10
+#define VR_COPY_COLV_X   (1u << 10)  /* the same for NEAREST: 16 consecutive VOXELS of a cell column in one aligned 16-byte word (1 byte per voxel): */
+#define VR_COPY_COLV_Y   (1u << 11)  /* one gather and one transparency test per sixteen samples */
+#define VR_COPY_COLV_Z   (1u << 12)
+#define VR_COPY_ALL      0x1fffu
+#define VR_COPY_KINDS    13
 int vr_hip_prepare(vr_ctx *ctx, uint32_t copies);
 /* Testing aid: the raw bytes of one resident brick copy (kind = bit index of its VR_COPY_* flag), so that a test can hold every copy
  * builder against a host-side construction of the layout, byte for byte.  *bytes_out (optional) = size of the copy; host_out may be

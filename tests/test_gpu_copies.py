@@ -117,6 +117,19 @@ def column_copy(vox, m):
     return out.reshape(-1)
 
 
+def column_voxel_copy(vox, m):
+    """NEAREST column windows along axis m: [block row bv][block bu][window w][column (v & 3, u & 3)] -> 16 consecutive voxels of the column
+    (march index 16w .. 16w+15, clamped at Nm - 1); columns beyond the volume hold the clamped edge columns."""
+    dims = vox.shape[::-1]
+    ua, va = (1 if m == 0 else 0), (1 if m == 2 else 2)
+    nu, nv, nm = dims[ua], dims[va], dims[m]
+    nbu, nbv, nw = (nu + 3) // 4, (nv + 3) // 4, (nm + 15) // 16
+    bv, bu, w, cv, cu, j = np.meshgrid(np.arange(nbv), np.arange(nbu), np.arange(nw), np.arange(4), np.arange(4), np.arange(16), indexing="ij")
+    idx = [None, None, None]
+    idx[ua], idx[va], idx[m] = np.minimum(bu * 4 + cu, nu - 1), np.minimum(bv * 4 + cv, nv - 1), np.minimum(w * 16 + j, nm - 1)
+    return vox[idx[2], idx[1], idx[0]].astype(np.uint8).reshape(-1)
+
+
 def _volume(shape, dtype, seed):
     rng = np.random.default_rng(seed)
     hi = 256 if dtype == np.uint8 else 65536
@@ -128,7 +141,7 @@ def test_u8_copies_equal_the_host_construction(vr, gpu, shape):
     vox = _volume(shape, np.uint8, 7)
     gpu.set_layout(vr.LAYOUT_BRICKED)
     gpu.set_volume(vox)
-    gpu.prepare(vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_QUAD_YZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y | vr.COPY_VOXEL | vr.COPY_COL_X | vr.COPY_COL_Y | vr.COPY_COL_Z)
+    gpu.prepare(vr.COPY_QUAD_XY | vr.COPY_QUAD_XZ | vr.COPY_QUAD_YZ | vr.COPY_RUN_Z | vr.COPY_RUN_Y | vr.COPY_VOXEL | vr.COPY_COL_X | vr.COPY_COL_Y | vr.COPY_COL_Z | vr.COPY_COLV_X | vr.COPY_COLV_Y | vr.COPY_COLV_Z)
     for plane in range(3):
         assert np.array_equal(gpu.download_copy(plane), quad_copy(vox, plane)), ("quad", plane)
     assert np.array_equal(gpu.download_copy(3), run_copy(vox, False)), "run z"
@@ -136,6 +149,7 @@ def test_u8_copies_equal_the_host_construction(vr, gpu, shape):
     assert np.array_equal(gpu.download_copy(5), voxel_copy(vox)), "voxel"
     for m in range(3):
         assert np.array_equal(gpu.download_copy(7 + m), column_copy(vox, m)), ("column windows along", "xyz"[m])
+        assert np.array_equal(gpu.download_copy(10 + m), column_voxel_copy(vox, m)), ("voxel column windows along", "xyz"[m])
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 32), (17, 40, 137)])

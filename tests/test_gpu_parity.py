@@ -186,7 +186,8 @@ def test_column_march_matches_oracle(vr, gpu, golden, oracle):
             gpu.set_window_buffer(w, h)
             for angles in poses + ((0.02, 0.0, 0.0), (90.0, 0.013, 0.0), (-45.0, -45.0, 0.0), (1.5, 2.5, 0.0)):
                 axis_aligned = angles in poses
-                for samp, kd, step_scale in ((vr.SAMPLE_TRILINEAR, 0.6, 1.0), (vr.SAMPLE_TRILINEAR_Q8, 0.0, 1.0), (vr.SAMPLE_TRILINEAR, 0.6, 0.37)):
+                for samp, kd, step_scale in ((vr.SAMPLE_TRILINEAR, 0.6, 1.0), (vr.SAMPLE_TRILINEAR_Q8, 0.0, 1.0), (vr.SAMPLE_TRILINEAR, 0.6, 0.37),
+                                             (vr.SAMPLE_NEAREST, 0.6, 1.0), (vr.SAMPLE_NEAREST, 0.0, 0.37)):       # NEAREST: windows of 16 voxels (colmarch_nearest_kernel)
                     p = golden.params(case, samp)
                     v = vr.custom_view(w, h, False, angles, 2.0)
                     for f in ("origin", "direction", "right_plane", "up_plane"):
@@ -596,8 +597,8 @@ def test_volume_info_and_release_of_the_linear_copy(vr, golden):
         r.prepare()                                                            # everything the policy has
         info = r.volume_info()
         assert info.copies == vr.COPY_ALL & ~vr.COPY_OCT and info.brick_copies == info.brick_copies_wanted == 3 and info.brick_planes == 7 and info.run_copy == 7
-        assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3 + 3 * (8 * 8 * 11 * 256)       # + three column-window copies
-        assert all(ms > 0 for ms in list(info.build_ms)[:6]) and info.build_ms[6] == 0 and all(ms > 0 for ms in list(info.build_ms)[7:10])
+        assert info.bricked_bytes == 3 * 4 * 32 ** 3 + 2 * (4 * 4 * 4 * 2304 + 16) + 32 ** 3 + 3 * (8 * 8 * 11 * 256) + 3 * (8 * 8 * 2 * 256)    # + the column-window copies (quad elements, voxels)
+        assert all(ms > 0 for ms in list(info.build_ms)[:6]) and info.build_ms[6] == 0 and all(ms > 0 for ms in list(info.build_ms)[7:13])
         assert info.copies_refused == 0 and info.upload_ms > 0
         before = [near, tri]
         r.release_linear_copy()

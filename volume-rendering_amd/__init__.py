@@ -12,7 +12,7 @@ The directory name contains a hyphen, so import it with
 from .binding import (  # noqa: F401
     VrError, VrParams, VrView, VrTiming, lib, library_path,
     SAMPLE_NEAREST, SAMPLE_TRILINEAR, SAMPLE_TRILINEAR_Q8, TF_SIZE, ESL_VOLUME_SIZE, LAYOUT_LINEAR, LAYOUT_BRICKED,
-    COPY_QUAD_XY, COPY_QUAD_XZ, COPY_QUAD_YZ, COPY_RUN_Z, COPY_RUN_Y, COPY_VOXEL, COPY_OCT, COPY_COL_X, COPY_COL_Y, COPY_COL_Z, COPY_ALL, COPY_NAMES, COPY_KINDS,
+    COPY_QUAD_XY, COPY_QUAD_XZ, COPY_QUAD_YZ, COPY_RUN_Z, COPY_RUN_Y, COPY_VOXEL, COPY_OCT, COPY_COL_X, COPY_COL_Y, COPY_COL_Z, COPY_COLV_X, COPY_COLV_Y, COPY_COLV_Z, COPY_ALL, COPY_NAMES, COPY_KINDS,
 )
 from .scene import Scene, benchmark_view, custom_view, whole_frame, band_partition  # noqa: F401
 from .renderer import HipRenderer, MultiRenderer  # noqa: F401
@@ -20,5 +20,5 @@ from .renderer import HipRenderer, MultiRenderer  # noqa: F401
 __all__ = [
     "VrError", "VrParams", "VrView", "VrTiming", "lib", "library_path", "SAMPLE_NEAREST", "SAMPLE_TRILINEAR", "SAMPLE_TRILINEAR_Q8",
     "TF_SIZE", "ESL_VOLUME_SIZE", "LAYOUT_LINEAR", "LAYOUT_BRICKED", "COPY_QUAD_XY", "COPY_QUAD_XZ", "COPY_QUAD_YZ", "COPY_RUN_Z", "COPY_RUN_Y",
-    "COPY_VOXEL", "COPY_OCT", "COPY_COL_X", "COPY_COL_Y", "COPY_COL_Z", "COPY_ALL", "COPY_NAMES", "COPY_KINDS", "Scene", "benchmark_view", "custom_view", "whole_frame", "band_partition", "HipRenderer", "MultiRenderer",
+    "COPY_VOXEL", "COPY_OCT", "COPY_COL_X", "COPY_COL_Y", "COPY_COL_Z", "COPY_COLV_X", "COPY_COLV_Y", "COPY_COLV_Z", "COPY_ALL", "COPY_NAMES", "COPY_KINDS", "Scene", "benchmark_view", "custom_view", "whole_frame", "band_partition", "HipRenderer", "MultiRenderer",
 ]

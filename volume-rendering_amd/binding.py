@@ -8,9 +8,10 @@ SAMPLE_TRILINEAR_Q8 = 2  # vr_sampling.VR_SAMPLE_TRILINEAR_Q8 — the same with 
 LAYOUT_LINEAR = 0        # vr_layout
 LAYOUT_BRICKED = 1
 # VR_COPY_* bits (vr_hip_prepare / vr_volume_info.copies): quad bricks per chunk plane, run bricks along z / y, voxel bricks
-COPY_QUAD_XY, COPY_QUAD_XZ, COPY_QUAD_YZ, COPY_RUN_Z, COPY_RUN_Y, COPY_VOXEL, COPY_OCT, COPY_COL_X, COPY_COL_Y, COPY_COL_Z, COPY_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1023
-COPY_NAMES = ("quad_xy", "quad_xz", "quad_yz", "run_z", "run_y", "voxel", "oct", "col_x", "col_y", "col_z")
-COPY_KINDS = 10
+COPY_QUAD_XY, COPY_QUAD_XZ, COPY_QUAD_YZ, COPY_RUN_Z, COPY_RUN_Y, COPY_VOXEL, COPY_OCT, COPY_COL_X, COPY_COL_Y, COPY_COL_Z, COPY_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 8191
+COPY_COLV_X, COPY_COLV_Y, COPY_COLV_Z = 1024, 2048, 4096
+COPY_NAMES = ("quad_xy", "quad_xz", "quad_yz", "run_z", "run_y", "voxel", "oct", "col_x", "col_y", "col_z", "colv_x", "colv_y", "colv_z")
+COPY_KINDS = 13
 TF_SIZE = 128
 ESL_VOLUME_SIZE = 1024
 
@@ -51,7 +52,7 @@ class VrVolumeInfo(C.Structure):
                 ("layout", C.c_uint32), ("brick_copies", C.c_uint32), ("brick_copies_wanted", C.c_uint32), ("brick_planes", C.c_uint32),
                 ("linear_resident", C.c_uint32), ("run_copy", C.c_uint32), ("linear_bytes", C.c_uint64), ("bricked_bytes", C.c_uint64),
                 ("copies", C.c_uint32), ("copies_in_policy", C.c_uint32), ("copies_refused", C.c_uint32),
-                ("build_ms", C.c_float * 10), ("upload_ms", C.c_float)]
+                ("build_ms", C.c_float * 13), ("upload_ms", C.c_float)]
 
 
 class VrTiming(C.Structure):

@@ -182,8 +182,9 @@ enum : uint32_t { kPlaneXY = 0, kPlaneXZ = 1, kPlaneYZ = 2, kPlanes = 3 };
 // the brick copies a context may hold (bit i of vr_hip_prepare's mask / vr_volume_info::copies = copy i): quad bricks per chunk
 // plane, run bricks along z / y, voxel bricks
 enum : uint32_t { kCopyQuadXY = 0, kCopyQuadXZ = 1, kCopyQuadYZ = 2, kCopyRunZ = 3, kCopyRunY = 4, kCopyVoxel = 5, kCopyOct = 6,
-                  kCopyColX = 7, kCopyColY = 8, kCopyColZ = 9,        // column windows along x / y / z (kLayoutColumn)
-                  kCopyKinds = 10 };
+                  kCopyColX = 7, kCopyColY = 8, kCopyColZ = 9,        // column windows along x / y / z (kLayoutColumn), quad elements: TRILINEAR
+                  kCopyColVoxX = 10, kCopyColVoxY = 11, kCopyColVoxZ = 12,      // ... of plain voxels: NEAREST
+                  kCopyKinds = 13 };
 static_assert(kCopyKinds == VR_COPY_KINDS, "include/vr_hip.h VR_COPY_KINDS");
 // column windows (kLayoutColumn): lateral axes (u, v) of march axis m are the two other axes in increasing order
 // A lateral block is kColEdge x kColEdge cell columns: its windows are kColBlockBytes each and follow each other along m.  4 x 4 columns
@@ -194,16 +195,19 @@ static_assert(kCopyKinds == VR_COPY_KINDS, "include/vr_hip.h VR_COPY_KINDS");
 #endif
 constexpr uint32_t kColEdgeLog2 = VR_COL_EDGE_LOG2, kColEdge = 1u << kColEdgeLog2, kColEdgeMask = kColEdge - 1u;
 constexpr uint32_t kColCells = 3, kColWindowBytes = 16, kColRowBytes = kColEdge * kColWindowBytes, kColBlockBytes = kColEdge * kColRowBytes;       // cells per window; edge x edge columns x 16 bytes
+// NEAREST reads ONE voxel per sample: its column windows hold 16 consecutive voxels of the column (cells 16w .. 16w+15, the index
+// clamped at Nm - 1) in the same block / window geometry — one 16-byte gather and one transparency test per SIXTEEN samples, 1 byte per voxel.
+constexpr uint32_t kColVoxCells = 16;
 __host__ __device__ constexpr uint32_t col_blocks(uint32_t n) { return (n + kColEdgeMask) >> kColEdgeLog2; }
 __host__ __device__ constexpr uint32_t col_axis_u(uint32_t m) { return m == 0u ? 1u : 0u; }
 __host__ __device__ constexpr uint32_t col_axis_v(uint32_t m) { return m == 2u ? 1u : 2u; }
-__host__ __device__ inline uint32_t col_windows(uint32_t nm) { return (nm + kColCells - 1u) / kColCells; }
+__host__ __device__ inline uint32_t col_windows(uint32_t nm, uint32_t cells = kColCells) { return (nm + cells - 1u) / cells; }
 // The march prefetches windows past a ray's exit and addresses them by a running pointer without clamping the window index: inside
 // the copy that reads a neighbouring block's windows (never used: those samples lie outside every segment), at its two ends it reads
 // this much zeroed padding (64 windows).  The kernel bounds its window count by the windows left in march direction + kColSlots + 2 (colmarch_kernel).
 constexpr uint32_t kColPadBytes = 64u * kColBlockBytes;
-inline uint64_t col_copy_bytes(const uint32_t dim[3], uint32_t m) {      // without the padding
-	return (uint64_t) col_blocks(dim[col_axis_u(m)]) * col_blocks(dim[col_axis_v(m)]) * col_windows(dim[m]) * kColBlockBytes;
+inline uint64_t col_copy_bytes(const uint32_t dim[3], uint32_t m, bool voxels = false) {      // without the padding
+	return (uint64_t) col_blocks(dim[col_axis_u(m)]) * col_blocks(dim[col_axis_v(m)]) * col_windows(dim[m], voxels ? kColVoxCells : kColCells) * kColBlockBytes;
 }
 // bit position of coordinate bit k (0..2) of axis (0 = x, 1 = y, 2 = z)
 __host__ __device__ inline uint32_t brick_bit(uint32_t bytes_per_voxel, uint32_t plane, uint32_t axis, uint32_t k) {
@@ -240,7 +244,7 @@ hipError_t launch_brickify_oct(const void *linear, void *oct_bricks, uint32_t di
 hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_layout /* kLayoutRun | kLayoutRunY */, uint32_t dim_x, uint32_t dim_y,
                                uint32_t dim_z, hipStream_t stream);
 // linear -> column windows along axis m (1-byte voxels)
-hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
+hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, bool voxels /* NEAREST windows */, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream);
 // number of quad elements (each 4 * bytes_per_voxel bytes)
 inline uint64_t bricked_elems(uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
 	return (uint64_t) ((dim_x + kBrickEdge - 1) / kBrickEdge) * ((dim_y + kBrickEdge - 1) / kBrickEdge) *

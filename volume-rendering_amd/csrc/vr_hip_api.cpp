@@ -517,7 +517,8 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// host checks: the lateral drift over the longest possible segment stays below half a cell, a sample advances between 1/64 and 1 cell
 	// along the axis (the kernel re-checks both per wave and otherwise marches per lane), at most one cell per pixel (the 32-bit offsets
 	// of a wave's columns), no clamping instantiation.  Measured on the benchmark poses (full march, lit): 2.12 / 2.13 / 2.86 ms before.
-	if (p->sampling != VR_SAMPLE_NEAREST && bricked && c->bpv == 1 && !c->force_wide && !p->view.perspective && !p->esl && p->ray_threshold >= 1.0f &&
+	// NEAREST takes the same march over windows of 16 plain voxels (colmarch_nearest_kernel, kCopyColVox*): one gather per sixteen samples.
+	if (bricked && c->bpv == 1 && !c->force_wide && !p->view.perspective && !p->esl && p->ray_threshold >= 1.0f &&
 	    !a.clamp_fetch && c->column_force >= 0 && (c->brick_plane_force < 0 || c->column_force > 0)) {
 		const float half[3] = { a.half_x, a.half_y, a.half_z };
 		float d[3];
@@ -528,7 +529,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		for (int i = 0; i < 3; i++) if ((std::fabs(p->view.right_plane[i]) + std::fabs(p->view.up_plane[i])) * half[i] > 1.0f) take = false;
 		if (c->column_force == 0)                                          // per view: along the axis — 4 > 2 sqrt(3), the longest segment in k
 			for (int i = 0; i < 3; i++) if (i != m && d[i] * 4.0f >= 0.45f) take = false;
-		if (take && copy_possible(c, kCopyColX + (uint32_t) m)) {
+		if (take && copy_possible(c, (p->sampling == VR_SAMPLE_NEAREST ? kCopyColVoxX : kCopyColX) + (uint32_t) m)) {
 			a.layout = kLayoutColumn; a.col_axis = (uint32_t) m; a.brick_plane = (uint32_t) m;
 			dual_analytic = false; dual_stage = -1;
 		}
@@ -543,7 +544,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	}
 	if (a.layout != kLayoutLinear && brick_copy == nullptr) {
 		const uint32_t want = a.layout == kLayoutRun ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
-		                      a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? kCopyColX + a.col_axis : kCopyQuadXY + a.brick_plane;
+		                      a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? (p->sampling == VR_SAMPLE_NEAREST ? kCopyColVoxX : kCopyColX) + a.col_axis : kCopyQuadXY + a.brick_plane;
 		brick_copy = copy_for(c, want);
 		if (brick_copy == nullptr && want != kCopyQuadXY) {
 			a.layout = kLayoutBricked; a.brick_plane = kPlaneXY;
@@ -711,7 +712,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 		a.bc_base = (uint64_t) (uintptr_t) array - (a.layout == kLayoutColumn ? kColPadBytes : 0u);
 		a.bc_bytes = plan.reads_linear ? (c->vol_elems + volume_tail_slack(c->dim[0], c->dim[1])) * c->bpv :
 		             copy_bytes(c, a.layout == kLayoutRun || a.layout == kLayoutRunDual ? kCopyRunZ : a.layout == kLayoutRunY ? kCopyRunY : a.layout == kLayoutVoxel ? kCopyVoxel :
-		                           a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? kCopyColX + a.col_axis : kCopyQuadXY + a.brick_plane);
+		                           a.layout == kLayoutOct ? kCopyOct : a.layout == kLayoutColumn ? (p->sampling == VR_SAMPLE_NEAREST ? kCopyColVoxX : kCopyColX) + a.col_axis : kCopyQuadXY + a.brick_plane);
 		if (a.layout == kLayoutColumn) a.bc_bytes += 2ull * kColPadBytes;
 		a.bc_alt_bytes = a.alt_copy ? copy_bytes(c, kCopyRunY) : 0;
 		a.bc_fault = c->bc_fault; a.bc_ntiles = ntiles;
@@ -776,7 +777,7 @@ hipError_t drain(vr_ctx *c) {
 
 void free_bricks(vr_ctx *c) {
 	for (uint32_t k = 0; k < kCopyKinds; k++) {
-		if (c->copy[k]) { (void) hipFree(k >= kCopyColX && k <= kCopyColZ ? (uint8_t *) c->copy[k] - kColPadBytes : (uint8_t *) c->copy[k]); c->copy[k] = nullptr; }
+		if (c->copy[k]) { (void) hipFree(k >= kCopyColX && k <= kCopyColVoxZ ? (uint8_t *) c->copy[k] - kColPadBytes : (uint8_t *) c->copy[k]); c->copy[k] = nullptr; }
 		c->copy_build_ms[k] = 0; c->copy_failed[k] = false;
 	}
 }
@@ -788,6 +789,7 @@ uint64_t copy_bytes(const vr_ctx *c, uint32_t kind) {
 	if (kind == kCopyVoxel) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * c->bpv;
 	if (kind == kCopyOct) return bricked_elems(c->dim[0], c->dim[1], c->dim[2]) * 8 * c->bpv;
 	if (kind >= kCopyColX && kind <= kCopyColZ) return col_copy_bytes(c->dim, kind - kCopyColX);
+	if (kind >= kCopyColVoxX && kind <= kCopyColVoxZ) return col_copy_bytes(c->dim, kind - kCopyColVoxX, true);
 	return run_copy_bytes(c->dim[0], c->dim[1], c->dim[2]);
 }
 
@@ -798,7 +800,7 @@ bool copy_in_policy(const vr_ctx *c, uint32_t kind) {
 	if (kind == kCopyQuadXY) return true;
 	if (kind == kCopyVoxel) return max_dim_of(c) <= 2048u;
 	if (kind == kCopyOct) return c->bpv == 2 && max_dim_of(c) <= 2048u;
-	if (kind >= kCopyColX && kind <= kCopyColZ) return c->bpv == 1 && max_dim_of(c) <= 2048u;
+	if (kind >= kCopyColX && kind <= kCopyColVoxZ) return c->bpv == 1 && max_dim_of(c) <= 2048u;
 	if (kind == kCopyQuadXZ || kind == kCopyQuadYZ) return c->bpv == 1 && max_dim_of(c) <= 1024u && copy_bytes(c, kind) <= (1ull << 32);
 	return c->bpv == 1 && max_dim_of(c) <= 1024u;
 }
@@ -822,7 +824,7 @@ int build_copy(vr_ctx *c, uint32_t kind) {
 		if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes >= free_b || free_b - bytes < total_b / 2) { (void) hipGetLastError(); c->copy_failed[kind] = true; return VR_ERR_ALLOC; }
 	}
 	void *dst = nullptr;
-	const bool column = kind >= kCopyColX && kind <= kCopyColZ;          // column windows: zeroed padding in front and behind (vr_device.h kColPadBytes)
+	const bool column = kind >= kCopyColX && kind <= kCopyColVoxZ;       // column windows: zeroed padding in front and behind (vr_device.h kColPadBytes)
 	if (hipMalloc(&dst, bytes + (column ? 2ull * kColPadBytes : 0ull)) != hipSuccess) { (void) hipGetLastError(); c->copy_failed[kind] = true; return fail(c, VR_ERR_ALLOC, "brick copy allocation failed"); }
 	hipError_t e = hipSuccess;
 	if (column) {
@@ -835,7 +837,8 @@ int build_copy(vr_ctx *c, uint32_t kind) {
 		if (kind <= kCopyQuadYZ) e = launch_brickify(c->vol, dst, c->bpv, kind - kCopyQuadXY, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else if (kind == kCopyVoxel) e = launch_brickify_voxel(c->vol, dst, c->bpv, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else if (kind == kCopyOct) e = launch_brickify_oct(c->vol, dst, c->dim[0], c->dim[1], c->dim[2], c->stream);
-		else if (kind >= kCopyColX && kind <= kCopyColZ) e = launch_build_column(c->vol, dst, kind - kCopyColX, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else if (kind >= kCopyColX && kind <= kCopyColZ) e = launch_build_column(c->vol, dst, kind - kCopyColX, false, c->dim[0], c->dim[1], c->dim[2], c->stream);
+		else if (kind >= kCopyColVoxX && kind <= kCopyColVoxZ) e = launch_build_column(c->vol, dst, kind - kCopyColVoxX, true, c->dim[0], c->dim[1], c->dim[2], c->stream);
 		else e = launch_brickify_run(c->vol, dst, kind == kCopyRunY ? kLayoutRunY : kLayoutRun, c->dim[0], c->dim[1], c->dim[2], c->stream);
 	}
 	if (e == hipSuccess) e = hipEventRecord(c->aux_stop, c->stream);

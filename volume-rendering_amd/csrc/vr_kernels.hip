@@ -1505,6 +1505,338 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	if (out_index != 0xffffffffu) ((ConstKernelArguments) dense_args())->out[out_index] = rgba;
 }
 
+// ---- the column march for NEAREST sampling (round 4) — the mode that is bit-exact against the reference's own CPURenderer ------------
+//
+// The same march as colmarch_kernel (wave-uniform k in 64-sample batches, one managed 16-byte gather per lane and window, event windows
+// for lanes that change their column), with Model::sample_data's arithmetic (ModelBase.h:17-23, CPURenderer.cpp:17,24,38): position =
+// origin + direction * k (two roundings), cell = map_float_int((position + 1) / 2, dim).  A sample needs ONE voxel, so a window is 16
+// consecutive voxels of the lane's column (vr_device.h kColVoxCells): one gather and one transparency test per SIXTEEN samples, and the
+// copy is 1 byte per voxel.  The cell along m is tracked UNclamped (a clamped index would stick to the last window and the window loops
+// rely on the samples moving on), except for the one value Nm that map_float_int folds onto Nm - 1 for positions on the far face.
+__device__ __forceinline__ void managed_load8_at(uint32_t &dst, uint64_t address) {       // zero-extended byte by 64-bit address
+	asm volatile("global_load_ubyte %0, %1, off" : "=&v"(dst) : "v"(address));
+}
+
+template <int M, bool FLIPS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(VR_COL_WAVES, 8)))
+void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, const float *__restrict__ tf_g, uint32_t *__restrict__ out) {
+	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
+	constexpr int kCells = (int) kColVoxCells;
+	typedef const RayKernelArgs __attribute__((address_space(4))) *ConstArgs;
+	__shared__ f4 tf_l[VR_TF_SIZE];
+	__shared__ float unit_l[256];                                       // unit[s] = (float) s / 255.0f, the quotient Raycaster::shade forms twice per shaded sample
+	{
+		const uint32_t t = threadIdx.x;
+		if (t < VR_TF_SIZE) tf_l[t] = ((const f4 *) tf_g)[t];
+		if (t < 256u) unit_l[t] = (float) t / 255.0f;
+	}
+	__syncthreads();
+	uint32_t tile_x, tile_y;
+	tile_to_xy(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, qd = lane >> 4;
+	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;
+	const uint32_t order = a.lane_map & 3u;
+	if (order == kLaneBlocks) { gu = ((lane >> 1) & 2u) | (lane & 1u); gv = ((lane >> 2) & 2u) | ((lane >> 1) & 1u); }
+	else if (order == kLaneColumns) { const uint32_t t = gu; gu = gv; gv = t; }
+	const uint32_t wx = (qd & 1u) * 4u + gu, wy = (qd >> 1) * 4u + gv, ox = (wave & 3u) * 8u, oy = (wave >> 2) * 8u;
+	const uint32_t lx = tile_x * 32u + ox + wx - a.phase_x, ly = tile_y * 16u + oy + wy - a.phase_y;
+	const bool in_frame = lx < a.p.out_width && ly < a.p.out_rows;
+	const uint32_t band = ly / a.p.band_rows;
+	const uint32_t gy = (band * a.p.band_stride + a.p.band_first) * a.p.band_rows + (ly - band * a.p.band_rows);
+	const uint32_t gx = a.p.x0 + lx;
+	uint32_t out_index = in_frame ? ly * a.p.out_width + lx : 0xffffffffu;
+
+	bool alive = in_frame && gx < a.p.view.width && gy < a.p.view.height;
+	const f3 dir = ld3(a.p.view.direction);
+	uint32_t pixel = (gy << 16) | (gx & 0xffffu);
+	auto origin_of = [](ConstArgs q, uint32_t px) {
+		const float fx = (float) ((int) (px & 0xffffu) - (int) (q->p.view.width / 2u)), fy = (float) ((int) (px >> 16) - (int) (q->p.view.height / 2u));
+		f3 o = mk3(q->p.view.origin[0] + q->p.view.right_plane[0] * fx, q->p.view.origin[1] + q->p.view.right_plane[1] * fx, q->p.view.origin[2] + q->p.view.right_plane[2] * fx);
+		return mk3(o.x + q->p.view.up_plane[0] * fy, o.y + q->p.view.up_plane[1] * fy, o.z + q->p.view.up_plane[2] * fy);
+	};
+	const f3 origin = origin_of((ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(), pixel);
+	float kx = 0, ky = 0;
+	alive = alive && intersect(origin, dir, kx, ky);
+	const float step = a.p.ray_step;
+	alive = alive && (ky + step > ky);
+	ky = flmin(ky, kx + step * (float) kMaxRaySteps);
+	const uint64_t alive_mask = __builtin_amdgcn_ballot_w64(alive);
+	if (alive_mask == 0ull) { if (in_frame) out[out_index] = 0u; return; }
+	if (!alive) ky = -1.0f;
+
+	auto uni = [](float v) { return __uint_as_float(rfl(__float_as_uint(v))); };
+	const float dm = comp3<M>(dir), du = comp3<U>(dir), dv = comp3<V>(dir);            // kernel arguments: scalar
+	const float om = comp3<M>(origin), ou = comp3<U>(origin), ov = comp3<V>(origin);
+	const uint32_t dim_u = U == 0 ? a.dim_x : a.dim_y, dim_v = V == 1 ? a.dim_y : a.dim_z, dim_m = M == 0 ? a.dim_x : (M == 1 ? a.dim_y : a.dim_z);
+	const float half_m = M == 0 ? a.half_x : (M == 1 ? a.half_y : a.half_z);
+	const uint32_t nbu = col_blocks(dim_u), nw = col_windows(dim_m, kColVoxCells);
+	const uint64_t stride_u = (uint64_t) nw * kColBlockBytes, stride_v = (uint64_t) nbu * stride_u;
+	auto f_u = [&](int c) { return (uint64_t) ((uint32_t) c >> kColEdgeLog2) * stride_u + ((uint32_t) c & kColEdgeMask) * kColWindowBytes; };
+	auto f_v = [&](int c) { return (uint64_t) ((uint32_t) c >> kColEdgeLog2) * stride_v + ((uint32_t) c & kColEdgeMask) * kColRowBytes; };
+
+	f4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+	uint64_t live = alive_mask;
+	float k = kx;
+	// transfer_fn[sample / TF_RATIO] (CPURenderer.cpp:31) is (0,0,0,0) for sample <= opaque_above; the per-WINDOW test is the weaker
+	// "every voxel below the largest power of two <= opaque_above + 1" (a mask on the packed bytes; windows that fail it test per sample)
+	const int opaque_above = ((int) a.tf_zero_below + 1) * VR_TF_RATIO - 1;
+	uint32_t near_mask = 0u, near_cmp = 1u;                             // nothing may be skipped: 0 != 1 always
+	if (opaque_above >= 0) { const uint32_t p2 = 1u << (31 - __builtin_clz((uint32_t) opaque_above + 1u)); near_mask = (0xffu & ~(p2 - 1u)) * 0x01010101u; near_cmp = 0u; }
+
+	auto dense_args = []() { ConstArgs q = (ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+	struct KernelArguments { RayKernelArgs a; const uint8_t *copy; const float *tf_g; uint32_t *out; };
+	typedef const KernelArguments __attribute__((address_space(4))) *ConstKernelArguments;
+	// address of the voxel Model::sample_data reads for a position (every index clamped: any position is in bounds)
+	auto voxel_address = [&](ConstArgs q, f3 pos) {
+		const uint32_t ix = map_float_int((pos.x + 1) * 0.5f, q->dim_x), iy = map_float_int((pos.y + 1) * 0.5f, q->dim_y), iz = map_float_int((pos.z + 1) * 0.5f, q->dim_z);
+		const uint32_t iu = U == 0 ? ix : iy, iv = V == 1 ? iy : iz, im = M == 0 ? ix : (M == 1 ? iy : iz);
+		const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
+		const uint32_t block = ((iv >> kColEdgeLog2) * col_blocks(qdim_u) + (iu >> kColEdgeLog2)) * col_windows(qdim_m, kColVoxCells) + (im >> 4);
+		const uint8_t *p = ((ConstKernelArguments) q)->copy + ((uint64_t) block * kColBlockBytes + (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + (im & 15u));
+		return VR_BC_POINTER(a, const uint8_t *, p, 1u);
+	};
+	auto position = [&](ConstArgs q, float kk) {                         // CPURenderer.cpp:17,24,38: origin + direction * k, two roundings per axis
+		const f3 o = origin_of(q, pixel);
+		return mk3(o.x + q->p.view.direction[0] * kk, o.y + q->p.view.direction[1] * kk, o.z + q->p.view.direction[2] * kk);
+	};
+	// one sample at `k` whose voxel is s: the general kernel's NEAREST body from the transparency test on (CPURenderer.cpp:29-39)
+	auto sample = [&](uint32_t s) {
+		if ((__builtin_amdgcn_sicmp((int) s, opaque_above, kIcmpSGT) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
+			ConstArgs q = dense_args();
+			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);
+			uint32_t idx = s / VR_TF_RATIO;
+			asm volatile("" : "+v"(idx));
+			f4 cur = tf_l[idx & (VR_TF_SIZE - 1u)];
+			const float kd = q->p.light_kd;
+			const uint64_t shaded = kd > 0.01f ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
+			if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
+				pin(pixel);
+				const f3 pt = position(q, k);
+				const f3 d = mk3(q->p.view.light_pos[0] - pt.x, q->p.view.light_pos[1] - pt.y, q->p.view.light_pos[2] - pt.z);
+				const float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+				const f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
+				const f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
+				const uint32_t s_l = *voxel_address(q, ps);
+				const float sl = unit_l[s_l], sc = unit_l[s & 255u];                          // RaycasterBase.h:93-96
+				const float diffuse = select_lanes(shaded, (sl - sc) * kd);
+				cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
+			}
+			const float t = select_lanes(live, 1 - acc.w);                                    // CPURenderer.cpp:34
+			acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
+			acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
+			live &= ~__builtin_amdgcn_fcmpf(acc.w, q->p.ray_threshold, kFcmpOGT);             // CPURenderer.cpp:35-36
+		}
+	};
+
+	// -- can this wave take the column path?  (all live lanes share kx and the origin's component along m: one k sequence, one cell along m)
+	const int leader = __builtin_ctzll(alive_mask);
+	const float kx_l = rlane(kx, leader), om_l = rlane(om, leader);
+	bool ok = __builtin_amdgcn_ballot_w64(alive && (__float_as_uint(kx) != __float_as_uint(kx_l) || __float_as_uint(om) != __float_as_uint(om_l))) == 0ull;
+	const float advance = __builtin_fabsf(dm * half_m) * step;
+	ok = ok && __builtin_amdgcn_ballot_w64(!(advance >= (1.0f / 64.0f) && advance <= 1.0f)) == 0ull;
+	// the cell along m of the wave's sample at kk: map_float_int's product by truncation, NOT clamped, but for the value Nm (positions on
+	// the far face, folded onto Nm - 1 like map_float_int does)
+	auto cell_m = [&](float kk) { const int c = (int) (((om_l + dm * kk) + 1.0f) * half_m); return c == (int) dim_m ? (int) dim_m - 1 : c; };
+	auto cell_lat = [&](float kk, float oc, float dc, uint32_t n) { return (int) map_float_int(((oc + dc * kk) + 1) * 0.5f, n); };
+	int cu0 = cell_lat(kx, ou, du, dim_u), cv0 = cell_lat(kx, ov, dv, dim_v);
+	int cu1 = cell_lat(ky, ou, du, dim_u), cv1 = cell_lat(ky, ov, dv, dim_v);
+	{
+		const int lu = __builtin_amdgcn_readlane(cu0, leader), lv = __builtin_amdgcn_readlane(cv0, leader);
+		if (!alive) { cu0 = cu1 = lu; cv0 = cv1 = lv; }
+	}
+	const uint64_t flips_u = __builtin_amdgcn_ballot_w64(cu0 != cu1), flips_v = __builtin_amdgcn_ballot_w64(cv0 != cv1);
+	ok = ok && __builtin_amdgcn_ballot_w64((cu1 - cu0) * (cu1 - cu0) > 1 || (cv1 - cv0) * (cv1 - cv0) > 1) == 0ull;
+	const int64_t ref = (int64_t) (f_u(__builtin_amdgcn_readlane(cu0, leader)) + f_v(__builtin_amdgcn_readlane(cv0, leader)));
+	const int64_t rel0 = (int64_t) (f_u(cu0) + f_v(cv0)) - ref;
+	const int64_t du64 = (int64_t) f_u(cu1) - (int64_t) f_u(cu0), dv64 = (int64_t) f_v(cv1) - (int64_t) f_v(cv0);
+	{
+		const int64_t lim = 1ll << 28;
+		ok = ok && __builtin_amdgcn_ballot_w64(rel0 <= -lim || rel0 >= lim || du64 <= -lim || du64 >= lim || dv64 <= -lim || dv64 >= lim) == 0ull;
+	}
+	const bool has_flips = (flips_u | flips_v) != 0ull;
+	auto per_lane_march = [&]() {                                        // exact, unpipelined: waves that straddle two kx values, forced testing
+		while (live != 0ull) {
+			ConstArgs q = dense_args();
+			const uint32_t s = *voxel_address(q, position(q, k));
+			sample(s);
+			k += step;
+			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);
+		}
+	};
+	if (ok) {
+		const uint32_t voff0 = (uint32_t) (rel0 + (1ll << 30));
+		uint64_t s_base;
+		{
+			const uint64_t b = (uint64_t) (uintptr_t) copy + (uint64_t) ref - (1ull << 30);
+			s_base = ((uint64_t) rfl((uint32_t) (b >> 32)) << 32) | rfl((uint32_t) b);
+		}
+		const int dsign = (__float_as_uint(dm) >> 31) != 0u ? -1 : 1;
+		auto window_of = [](int lc) { return lc >> 4; };                  // floor(cell / 16), also below 0
+		constexpr int kNoEvent = 0x7fffffff;
+		int key_u = kNoEvent, key_v = kNoEvent;
+		auto bisect = [&](bool flipping, int c0, float oc, float dc, uint32_t n) {
+			uint32_t lo = __float_as_uint(kx), hi = __float_as_uint(ky);
+			if (!flipping) hi = lo;
+			for (int it = 0; it < 34 && __builtin_amdgcn_ballot_w64(hi - lo > 1u) != 0ull; it++) {
+				const uint32_t mid = lo + ((hi - lo) >> 1);
+				const bool same = cell_lat(__uint_as_float(mid), oc, dc, n) == c0;
+				if (hi - lo > 1u) { if (same) lo = mid; else hi = mid; }
+			}
+			return flipping ? dsign * window_of(cell_m(__uint_as_float(hi))) : kNoEvent;
+		};
+		if (FLIPS && flips_u != 0ull) key_u = bisect(cu0 != cu1, cu0, ou, du, dim_u);
+		if (FLIPS && flips_v != 0ull) key_v = bisect(cv0 != cv1, cv0, ov, dv, dim_v);
+		int events = kNoEvent;
+		bool events_ok = true;
+		if (FLIPS && has_flips) {
+			const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+			int last = (int) 0x80000000, count = 0;
+			#pragma nounroll
+			for (; count < 64; count++) {
+				int cand = key_u > last ? key_u : kNoEvent;
+				if (key_v > last && key_v < cand) cand = key_v;
+				#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1) { const int other = __shfl_xor(cand, d, 64); cand = other < cand ? other : cand; }
+				cand = (int) rfl((uint32_t) cand);
+				if (cand == kNoEvent) break;
+				events = lane_i == (uint32_t) count ? cand : events;
+				last = cand;
+			}
+			events_ok = count < 64;
+		}
+		uint32_t flipinfo = 0x00ffffffu;                                  // colmarch_kernel's packing: keys + 1024, block-edge bits, directions
+		if (FLIPS && has_flips) {
+			const uint32_t pu = key_u == kNoEvent ? 0xfffu : (uint32_t) (key_u + 1024) & 0xfffu, pv = key_v == kNoEvent ? 0xfffu : (uint32_t) (key_v + 1024) & 0xfffu;
+			const bool up_u = cu1 > cu0, up_v = cv1 > cv0;
+			const bool cross_u = ((uint32_t) cu0 & kColEdgeMask) == (up_u ? kColEdgeMask : 0u), cross_v = ((uint32_t) cv0 & kColEdgeMask) == (up_v ? kColEdgeMask : 0u);
+			flipinfo = pu | (pv << 12) | (cross_u ? 1u << 24 : 0u) | (cross_v ? 1u << 25 : 0u) | (up_u ? 1u << 28 : 0u) | (up_v ? 1u << 29 : 0u);
+			events_ok = events_ok && __builtin_amdgcn_ballot_w64((key_u != kNoEvent && (key_u < -1023 || key_u > 1023)) || (key_v != kNoEvent && (key_v < -1023 || key_v > 1023))) == 0ull;
+		}
+		// the wave-uniform sample sequence, 64 samples at a time (see colmarch_kernel: exact arithmetic progression inside a binade)
+		float kvec = 0.0f, knext = kx_l;
+		int wvec = 0;
+		auto refill = [&]() {
+			const uint32_t lane_i = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+			const float kbase = knext;
+			const float k1 = kbase + step, delta = k1 - kbase, low = step - delta;
+			const uint32_t e = __float_as_uint(kbase) >> 23;
+			const float half_ulp = __uint_as_float((e > 24u ? e - 24u : 1u) << 23);
+			const float kend = VR_FMA(64.0f, delta, kbase);
+			const bool fast = rfl((e > 24u && (__float_as_uint(kend) >> 23) == e && __builtin_fabsf(low) != half_ulp && delta > 0.0f) ? 1u : 0u) != 0u;
+			if (fast) { kvec = VR_FMA((float) lane_i, delta, kbase); knext = uni(kend); }
+			else {
+				float kc = kbase;
+				#pragma nounroll
+				for (uint32_t j = 0; j < 64u; j++) { kvec = lane_i == j ? kc : kvec; kc = kc + step; }
+				knext = uni(kc);
+			}
+			wvec = window_of(cell_m(kvec));
+		};
+		refill();
+		int pos = 0;
+		int cur = __builtin_amdgcn_readlane(wvec, 0);
+		cur = cur < 0 ? 0 : (cur > (int) nw - 1 ? (int) nw - 1 : cur);
+		int guard = (dsign > 0 ? (int) nw - cur : cur + 1) + 2 * kColSlots;          // hang / bounds guard, as in colmarch_kernel
+		int woff = cur * (int) kColBlockBytes;
+		auto march = [&](auto flips_tag) {
+			constexpr bool kFlips = decltype(flips_tag)::value;
+			uint32_t vo = voff0;
+			int issue_key = dsign * cur, issue_at = 0, issue_event = kFlips ? __builtin_amdgcn_readlane(events, 0) : kNoEvent;
+			int cons_at = 0, cons_event = issue_event;
+			auto event_delta = [&](int event) {
+				ConstArgs q = dense_args();
+				const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
+				const uint32_t stride_u32 = col_windows(qdim_m, kColVoxCells) * kColBlockBytes, stride_v32 = col_blocks(qdim_u) * stride_u32;
+				const uint32_t want = (uint32_t) (event + 1024) & 0xfffu;
+				const uint32_t hit_u = (uint32_t) ((int) (((flipinfo ^ want) & 0xfffu) - 1u) >> 31), hit_v = (uint32_t) ((int) ((((flipinfo >> 12) ^ want) & 0xfffu) - 1u) >> 31);
+				const uint32_t mag_u = kColWindowBytes + ((flipinfo >> 24) & 1u) * (stride_u32 - kColRowBytes), mag_v = kColRowBytes + ((flipinfo >> 25) & 1u) * (stride_v32 - kColBlockBytes);
+				const uint32_t neg_u = ((flipinfo >> 28) & 1u) - 1u, neg_v = ((flipinfo >> 29) & 1u) - 1u;
+				return (((mag_u ^ neg_u) - neg_u) & hit_u) + (((mag_v ^ neg_v) - neg_v) & hit_v);
+			};
+			auto issue = [&](u32x4 &dst) {
+				if (kFlips) {
+					while (issue_key > issue_event) { vo += event_delta(issue_event); issue_at++; issue_event = __builtin_amdgcn_readlane(events, issue_at & 63); }
+					issue_key++;
+				}
+				const uint32_t lane_offset = vo + (uint32_t) woff;
+#if defined(VR_BOUNDS_CHECK)
+				managed_load128(dst, VR_BC_ADDRESS(a, s_base + lane_offset, 16u));
+#else
+				managed_load128_s(dst, lane_offset, s_base);
+#endif
+				woff += dsign * (int) kColBlockBytes;
+			};
+			u32x4 slot[kColSlots];
+			slot[kColSlots - 1] = (u32x4) (0u);
+			static_for<0, kColDepth>([&](auto j) { issue(slot[j.value]); });
+			auto window_step = [&](auto jc) {
+				constexpr int c = decltype(jc)::value, n = (c + kColDepth) % kColSlots;
+				issue(slot[n]);
+				__builtin_amdgcn_sched_barrier(0);
+				pin(slot[c]); managed_wait<kColDepth>(); pin(slot[c]);
+				const u32x4 o = slot[c];
+				if (c == 0) live &= __builtin_amdgcn_fcmpf(rlane(kvec, pos), ky, kFcmpOLE);
+				bool careful = false;
+				if (kFlips) {
+					const int key = issue_key - (kColDepth + 1);
+					while (key > cons_event) { cons_at++; cons_event = __builtin_amdgcn_readlane(events, cons_at & 63); }
+					careful = key == cons_event;
+				}
+				const uint32_t all16 = (o.x | o.y | o.z | o.w) & near_mask;
+				bool dense = careful;
+				if ((__builtin_amdgcn_uicmp(all16, near_cmp, kIcmpNE) & live) != 0ull) dense = dense || VR_OPEN_LANES(acc.w, live) != 0ull;
+				// a window holds at most 16 * 64 + 1 samples (a sample advances >= 1/64 cell): it ends within kCells + 2 batches — a hang guard
+				if (!dense) {
+					for (int batches = 0; batches < kCells + 2; batches++) {
+						pos += __builtin_popcountll(__builtin_amdgcn_ballot_w64(wvec == cur));
+						if (pos < 64) break;
+						refill(); pos = 0;
+					}
+					pos = pos < 64 ? pos : 63;
+				} else {
+					const int first = cur * kCells;
+					for (int batches = 0; batches < kCells + 2; batches++) {
+						const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wvec == cur));
+						for (int i = pos; i < pos + cnt; i++) {
+							k = rlane(kvec, i);
+							if (kFlips && careful) {                            // the voxel of each lane's true column, explicitly
+								ConstArgs q = dense_args();
+								uint32_t s;
+								managed_load8_at(s, (uint64_t) (uintptr_t) voxel_address(q, position(q, k)));
+								pin(s); managed_wait<0>(); pin(s);
+								sample(s);
+							} else {
+								const uint32_t sub = (uint32_t) ((int) rfl((uint32_t) cell_m(k)) - first) & 15u;      // the sample's voxel inside the window (uniform)
+								const uint32_t word = (sub >> 2) == 0u ? o.x : ((sub >> 2) == 1u ? o.y : ((sub >> 2) == 2u ? o.z : o.w));
+								sample((word >> ((sub & 3u) * 8u)) & 0xffu);
+							}
+						}
+						pos += cnt;
+						if (pos < 64) break;
+						refill(); pos = 0;
+					}
+					pos = pos < 64 ? pos : 63;
+				}
+				cur += dsign;
+			};
+			while (live != 0ull && guard > 0) {
+				static_for<0, kColSlots>(window_step);
+				guard -= kColSlots;
+			}
+			static_for<0, kColSlots>([&](auto j) { pin(slot[j.value]); });
+			managed_wait<0>();
+			static_for<0, kColSlots>([&](auto j) { pin(slot[j.value]); });
+		};
+		if (!events_ok || (has_flips && !FLIPS)) per_lane_march();
+		else march(std::integral_constant<bool, FLIPS>());
+	} else per_lane_march();
+	uint32_t ky_bits = __float_as_uint(ky);
+	pin(ky_bits, out_index);
+	uint32_t rgba = 0;
+	if (__uint_as_float(ky_bits) > 0.0f) rgba = map_float_int(acc.x, 256) | (map_float_int(acc.y, 256) << 8) | (map_float_int(acc.z, 256) << 16) | (map_float_int(acc.w, 256) << 24);
+	if (out_index != 0xffffffffu) ((ConstKernelArguments) dense_args())->out[out_index] = rgba;
+}
+
 // Which instantiation a frame runs: ONE selector, visited by the launcher and by the host's questions about the launch (does it read
 // the linear array?  how many workgroup tiles?), so the answers cannot drift from what is launched.  `visit` is called with four
 // std::integral_constant tags <SAMPLING, BPV, ADDR, LAYOUT> and a bool: true = the variant reads `linear`, false = the brick copy.
@@ -1595,6 +1927,12 @@ hipError_t launch_raymarch(const RayKernelArgs &args, const void *linear, const 
 		// lateral direction components exactly 0: no lane can change its column — the kernel without the flip logic
 		const uint32_t m = a.col_axis;
 		const bool flips = a.p.view.direction[m == 0u ? 1 : 0] != 0.0f || a.p.view.direction[m == 2u ? 1 : 2] != 0.0f;
+		if (a.p.sampling == VR_SAMPLE_NEAREST) {                          // voxel windows (kCopyColVoxX ..)
+			if (m == 0u) { if (flips) go(colmarch_nearest_kernel<0, true>); else go(colmarch_nearest_kernel<0, false>); }
+			else if (m == 1u) { if (flips) go(colmarch_nearest_kernel<1, true>); else go(colmarch_nearest_kernel<1, false>); }
+			else { if (flips) go(colmarch_nearest_kernel<2, true>); else go(colmarch_nearest_kernel<2, false>); }
+			return hipGetLastError();
+		}
 		auto pick = [&](auto sampling, auto axis) {
 			constexpr int S = decltype(sampling)::value, AX = decltype(axis)::value;
 			if (flips) go(colmarch_kernel<S, AX, true>); else go(colmarch_kernel<S, AX, false>);
@@ -1851,24 +2189,26 @@ hipError_t launch_brickify_run(const void *linear, void *run_copy, uint32_t run_
 // the upper faces, where the interpolation weight is exactly 0) with loads that are contiguous along x — x is u for m = y, z and the march
 // axis itself for m = x, hence the two tile shapes — then writes the windows with 16-byte stores in copy order: thread t -> (block, window,
 // column), 256 contiguous bytes per (block, window), a block's windows back to back.  Bound: HBM, bytes = linear + copy.
-template <int M> struct ColBuildCfg {
-	static constexpr uint32_t nbu = (M == 0 ? 16u : 128u) / kColEdge, nwin = M == 0 ? 85u : 8u;        // 16 / 128 columns along u per workgroup
-	static constexpr uint32_t tu = kColEdge * nbu + 1u, tv = kColEdge + 1u, te = kColCells * nwin + 1u;
+// VOX: the NEAREST windows — 16 consecutive voxels of the column itself (no +1 neighbours), cells 16w .. 16w+15, index clamped at Nm - 1.
+template <int M, bool VOX> struct ColBuildCfg {
+	static constexpr uint32_t cells = VOX ? kColVoxCells : kColCells;
+	static constexpr uint32_t nbu = (M == 0 ? 16u : 128u) / kColEdge, nwin = M == 0 ? (VOX ? 16u : 85u) : (VOX ? 2u : 8u);        // 16 / 128 columns along u per workgroup
+	static constexpr uint32_t tu = kColEdge * nbu + (VOX ? 0u : 1u), tv = kColEdge + (VOX ? 0u : 1u), te = cells * nwin + (VOX ? 0u : 1u);
 	static constexpr uint32_t tx = M == 0 ? te : tu;                           // tile extent along x (the contiguous axis of the linear array)
 	static constexpr uint32_t pitch = (tx + 3u) / 4u * 4u + 4u;               // bytes per staged x-row (multiple of 4, rows shifted over the banks)
 	static constexpr uint32_t rows = M == 0 ? tu * tv : tv * te;              // staged rows
 };
 
-template <int M>
+template <int M, bool VOX>
 __global__ __launch_bounds__(256)
 void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ out, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z) {
-	typedef ColBuildCfg<M> S;
+	typedef ColBuildCfg<M, VOX> S;
 	constexpr int U = M == 0 ? 1 : 0;
 	__shared__ __attribute__((aligned(16))) uint8_t tile[S::rows * S::pitch];
 	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
-	const uint32_t nbu = col_blocks(dim[U]), nw = col_windows(dim[M]);
+	const uint32_t nbu = col_blocks(dim[U]), nw = col_windows(dim[M], S::cells);
 	const uint32_t bu0 = blockIdx.x * S::nbu, bv = blockIdx.y, w0 = blockIdx.z * S::nwin;
-	const uint32_t u0 = bu0 * kColEdge, v0 = bv * kColEdge, e0 = w0 * kColCells;
+	const uint32_t u0 = bu0 * kColEdge, v0 = bv * kColEdge, e0 = w0 * S::cells;
 	const uint32_t t = threadIdx.x;
 	// row r of the tile: m = y, z: r = dv * te + de holds u = u0 ..; m = x: r = dv * tu + du holds e = e0 ..  (x runs along the row either way)
 	auto row_of = [&](uint32_t du, uint32_t dv, uint32_t de) { return M == 0 ? dv * S::tu + du : dv * S::te + de; };
@@ -1904,23 +2244,41 @@ void column_build_kernel(const uint8_t *__restrict__ lin, uint4 *__restrict__ ou
 		uint32_t word[4];
 		#pragma unroll
 		for (uint32_t j = 0; j < 4u; j++) {
-			// element 3w + j, march index clamped at Nm - 1 (tile-relative: the staged index of the clamped element)
-			uint32_t e = e0 + w * kColCells + j;
-			if (e > dim[M] - 1u) e = dim[M] - 1u;
-			const uint32_t de = e - e0;
-			word[j] = at(du, dv, de) | (at(du + 1u, dv, de) << 8) | (at(du, dv + 1u, de) << 16) | (at(du + 1u, dv + 1u, de) << 24);
+			if (VOX) {                                                       // dword j = voxels 16w + 4j .. + 3 of the column
+				word[j] = 0u;
+				#pragma unroll
+				for (uint32_t b4 = 0; b4 < 4u; b4++) {
+					uint32_t e = e0 + w * S::cells + j * 4u + b4;
+					if (e > dim[M] - 1u) e = dim[M] - 1u;
+					word[j] |= at(du, dv, e - e0) << (8u * b4);
+				}
+			} else {
+				// element 3w + j, march index clamped at Nm - 1 (tile-relative: the staged index of the clamped element)
+				uint32_t e = e0 + w * S::cells + j;
+				if (e > dim[M] - 1u) e = dim[M] - 1u;
+				const uint32_t de = e - e0;
+				word[j] = at(du, dv, de) | (at(du + 1u, dv, de) << 8) | (at(du, dv + 1u, de) << 16) | (at(du + 1u, dv + 1u, de) << 24);
+			}
 		}
 		out[((uint64_t) ((uint64_t) bv * nbu + bu0 + b) * nw + w0 + w) * kCols + col] = make_uint4(word[0], word[1], word[2], word[3]);
 	}
 }
 
-hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
+hipError_t launch_build_column(const void *linear, void *col_copy, uint32_t axis, bool voxels, uint32_t dim_x, uint32_t dim_y, uint32_t dim_z, hipStream_t stream) {
 	const uint32_t dim[3] = { dim_x, dim_y, dim_z };
-	const uint32_t nbu = col_blocks(dim[col_axis_u(axis)]), nbv = col_blocks(dim[col_axis_v(axis)]), nw = col_windows(dim[axis]);
-	auto grid = [&](uint32_t per_u, uint32_t per_w) { return dim3((nbu + per_u - 1u) / per_u, nbv, (nw + per_w - 1u) / per_w); };
-	if (axis == 0) hipLaunchKernelGGL(column_build_kernel<0>, grid(ColBuildCfg<0>::nbu, ColBuildCfg<0>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
-	else if (axis == 1) hipLaunchKernelGGL(column_build_kernel<1>, grid(ColBuildCfg<1>::nbu, ColBuildCfg<1>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
-	else hipLaunchKernelGGL(column_build_kernel<2>, grid(ColBuildCfg<2>::nbu, ColBuildCfg<2>::nwin), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
+	const uint32_t nbu = col_blocks(dim[col_axis_u(axis)]), nbv = col_blocks(dim[col_axis_v(axis)]), nw = col_windows(dim[axis], voxels ? kColVoxCells : kColCells);
+	auto go = [&](auto kernel, uint32_t per_u, uint32_t per_w) {
+		hipLaunchKernelGGL(kernel, dim3((nbu + per_u - 1u) / per_u, nbv, (nw + per_w - 1u) / per_w), dim3(256), 0, stream, (const uint8_t *) linear, (uint4 *) col_copy, dim_x, dim_y, dim_z);
+	};
+	if (voxels) {
+		if (axis == 0) go(column_build_kernel<0, true>, ColBuildCfg<0, true>::nbu, ColBuildCfg<0, true>::nwin);
+		else if (axis == 1) go(column_build_kernel<1, true>, ColBuildCfg<1, true>::nbu, ColBuildCfg<1, true>::nwin);
+		else go(column_build_kernel<2, true>, ColBuildCfg<2, true>::nbu, ColBuildCfg<2, true>::nwin);
+	} else {
+		if (axis == 0) go(column_build_kernel<0, false>, ColBuildCfg<0, false>::nbu, ColBuildCfg<0, false>::nwin);
+		else if (axis == 1) go(column_build_kernel<1, false>, ColBuildCfg<1, false>::nbu, ColBuildCfg<1, false>::nwin);
+		else go(column_build_kernel<2, false>, ColBuildCfg<2, false>::nbu, ColBuildCfg<2, false>::nwin);
+	}
 	return hipGetLastError();
 }
 

@@ -156,7 +156,7 @@ class HipRenderer:
         self._check(self._L.vr_hip_volume_info(self._ctx, C.byref(info)), "volume_info")
         return info
 
-    def prepare(self, copies=1023):
+    def prepare(self, copies=8191):
         """vr_hip_prepare: build the brick copies named by the VR_COPY_* bits now instead of on first use (default: all the
         layout policy has at this size).  A refused copy (HBM guard) raises VrError(VR_ERR_ALLOC); frames then read the next best."""
         self._check(self._L.vr_hip_prepare(self._ctx, int(copies)), "prepare")
@@ -250,7 +250,7 @@ class MultiRenderer:
     def sync(self):
         self._check(self._L.vr_hip_multi_sync(self._m), "sync")
 
-    def prepare(self, copies=1023):
+    def prepare(self, copies=8191):
         self._check(self._L.vr_hip_multi_prepare(self._m, int(copies)), "prepare")
 
     def context_timing(self, rank):
