@@ -47,6 +47,8 @@ def main():
     scene = vr.Scene().set_volume(dims=(n, n, n), minmax=mm)
     if a.mode == "nooptims":
         scene.set_modes(esl=False, ray_threshold=1.0)
+    elif a.mode == "ertonly":                                # VolR.cpp:288-290: early ray termination without leaping
+        scene.set_modes(esl=False)
     scene.set_modes(light_kd=a.light)
     r.set_transfer_fn(scene.tf, scene.esl)
     samp = {"trilinear": vr.SAMPLE_TRILINEAR, "q8": vr.SAMPLE_TRILINEAR_Q8}.get(a.sampling, vr.SAMPLE_NEAREST)

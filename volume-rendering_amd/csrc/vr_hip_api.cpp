@@ -518,7 +518,10 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 	// along the axis (the kernel re-checks both per wave and otherwise marches per lane), at most one cell per pixel (the 32-bit offsets
 	// of a wave's columns), no clamping instantiation.  Measured on the benchmark poses (full march, lit): 2.12 / 2.13 / 2.86 ms before.
 	// NEAREST takes the same march over windows of 16 plain voxels (colmarch_nearest_kernel, kCopyColVox*): one gather per sixteen samples.
-	if (bricked && c->bpv == 1 && !c->force_wide && !p->view.perspective && !p->esl && p->ray_threshold >= 1.0f &&
+	// Early ray termination alone is fine (the kernels clear a terminated lane's live bit like the general one; the k sequence stays shared);
+	// such frames give up the measured-cost tile order, which the column kernels do not take.
+	static const bool col_ert = [] { const char *e = getenv("VR_COL_ERT"); return e == nullptr || atoi(e) != 0; }();      // VR_COL_ERT=0: A/B
+	if (bricked && c->bpv == 1 && !c->force_wide && !p->view.perspective && !p->esl && (p->ray_threshold >= 1.0f || col_ert) &&
 	    !a.clamp_fetch && c->column_force >= 0 && (c->brick_plane_force < 0 || c->column_force > 0)) {
 		const float half[3] = { a.half_x, a.half_y, a.half_z };
 		float d[3];
