@@ -465,7 +465,7 @@ def run_rank(a):
                 "traffic_frac_of_peak": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
                 "kernel": "vr::raymarch_kernel + vr::colmarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernel_instantiations": "the frame's ONE launch is colmarch_kernel<sampling, axis, flips> for full-march frames of orthogonal views along a volume axis "
+                "kernel_instantiations": "the frame's ONE launch is colmarch_kernel<sampling, axis, flips> (NEAREST: colmarch_nearest_kernel<axis, flips>) for frames without leaping of orthogonal views along a volume axis "
                                          "(column windows: three of the eight benchmark views), else raymarch_kernel<sampling,1,0,L>: L = 1 quad bricks, 2 / 3 run bricks along z / y, "
                                          "6 both run copies chosen per block of tiles (orthogonal views that are not along an axis), 4 voxel bricks (NEAREST); "
                                          "kernel_ms = hipEvent mean over ALL timed launches (the views cycle)",

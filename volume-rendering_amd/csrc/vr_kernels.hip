@@ -565,6 +565,9 @@ __device__ __forceinline__ void tile_to_xy(uint32_t tiles_x, uint32_t tiles_y, u
 
 }
 
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ float rlane(float v, int lane) { return __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), lane)); }
+
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
 template <int SAMPLING, int BPV, int ADDR, int LAYOUT>
@@ -736,19 +739,69 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 	f3 pt = march_point<SAMPLING>(origin, dir, kx);
 
 	// -- empty space leaping loop (CPURenderer.cpp:18-25)
+	// Cooperative look-ahead for zero-leap chains (round 4).  A ray that runs exactly along a block face (rows / columns of pixels of the
+	// axis-aligned views; a few rays of every view) finds its block empty but its distance to the exit plane 0 at EVERY sample: it leaps by
+	// floor(0 / step) * step = 0 and probes again one step on — up to ~1000 dependent probes by one or two lanes of a wave that is alone
+	// on its SIMD at the end of the frame (the default mode's tail).  While at most VR_ESL_COOP_LANES lanes still probe and one of them
+	// has just leapt by exactly 0, the whole wave evaluates that ray's next positions — the j-th active lane the position j rounds of
+	// "+= 0; += step" on, formed EXACTLY (inside a binade fl(k + step) = k + round_u(step): an arithmetic progression, see colmarch_kernel;
+	// else by the sequential additions) — and the ray jumps to the first position whose probe is not again "empty block, zero leap",
+	// which the ordinary step below then evaluates.  Exact by construction.
+#ifndef VR_ESL_COOP_LANES
+#define VR_ESL_COOP_LANES 8
+#endif
 	if (a.p.esl) {
 		bool probing = alive;
-		while (__builtin_amdgcn_ballot_w64(probing) != 0ull) {
+		uint64_t zero_leap = 0ull, pm;                                  // lanes whose last probe leapt by exactly 0
+		int coop_pause = 0;                                             // a look-ahead that skipped fewer than four positions cost more than it saved: pause (perspective views: their chains are short)
+		while ((pm = __builtin_amdgcn_ballot_w64(probing)) != 0ull) {
+			const uint64_t chain = pm & zero_leap;
+			if (coop_pause > 0) coop_pause--;
+			else if (VR_ESL_COOP_LANES > 0 && chain != 0ull && __builtin_popcountll(pm) <= VR_ESL_COOP_LANES) {
+				const int leader = __builtin_ctzll(chain);
+				const f3 lo = mk3(rlane(origin.x, leader), rlane(origin.y, leader), rlane(origin.z, leader)), ld = mk3(rlane(dir.x, leader), rlane(dir.y, leader), rlane(dir.z, leader));
+				const float k0 = rlane(kx, leader), kend = rlane(ky, leader);
+				// (pixels outside the buffer have left the kernel: position j of the chain lives in the j-th ACTIVE lane)
+				const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) here, 0u));
+				float mine;
+				{
+					const float k1 = k0 + step, delta = k1 - k0, low = step - delta;
+					const uint32_t e = __float_as_uint(k0) >> 23;
+					const float half_ulp = __uint_as_float((e > 24u ? e - 24u : 1u) << 23), klast = VR_FMA(63.0f, delta, k0);
+					const bool fast = rfl((e > 24u && (__float_as_uint(klast) >> 23) == e && __builtin_fabsf(low) != half_ulp && delta > 0.0f) ? 1u : 0u) != 0u;
+					if (fast) mine = VR_FMA((float) rank, delta, k0);
+					else {
+						float run = k0;
+						mine = k0;
+						#pragma nounroll
+						for (uint32_t j = 1; j < 64u; j++) { run = run + step; mine = rank >= j ? run : mine; }
+					}
+				}
+				const f3 lp = march_point<SAMPLING>(lo, ld, mine);
+				const BlockIdx lb = block_index(a, lp);
+				bool goes_on = mine <= kend && block_empty(lds, lb);
+				if (goes_on) goes_on = leap_empty_space(a, lb, lp, ld) == 0.0f;
+				const uint64_t stops = here & ~__builtin_amdgcn_ballot_w64(goes_on);
+				const int first = stops != 0ull ? __builtin_ctzll(stops) : 63 - __builtin_clzll(here);      // the first position that does not go on (else the last: the step below re-evaluates it)
+				const float k_new = rlane(mine, first);
+				if ((int) lane == leader) { kx = k_new; pt = march_point<SAMPLING>(origin, dir, kx); }
+				if (__builtin_popcountll(here & ((1ull << first) - 1ull)) < 4) coop_pause = 24;
+			}
+			bool zl = false;
 			if (probing) {
 				const BlockIdx blk = block_index(a, pt);
 				if (kx <= ky && block_empty(lds, blk)) {
-					kx += leap_empty_space(a, blk, pt, dir);
+					const float leap = leap_empty_space(a, blk, pt, dir);
+					zl = leap == 0.0f;
+					kx += leap;
 					kx += step;
 					pt = march_point<SAMPLING>(origin, dir, kx);
 				} else {
 					probing = false;
 				}
 			}
+			zero_leap = __builtin_amdgcn_ballot_w64(zl);
 		}
 	}
 	alive = alive && (kx <= ky);                    // CPURenderer.cpp:26-27: fully empty ray — pixel keeps the clear value
@@ -1072,8 +1125,6 @@ __device__ __forceinline__ void managed_load128_s(u32x4 &dst, uint32_t byte_offs
 	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_offset), "s"(base));
 }
 template <int I> __device__ __forceinline__ float comp3(const f3 &v) { return I == 0 ? v.x : (I == 1 ? v.y : v.z); }
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
-__device__ __forceinline__ float rlane(float v, int lane) { return __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), lane)); }
 
 // the eight corner voxels of a sample out of the two quad elements along m (w0 = march index i, w1 = i + 1) -> trilinear value;
 // element bytes are (u,v), (u+1,v), (u,v+1), (u+1,v+1) with (u,v) the lateral axes of m in increasing order; lerps in x, y, z order
