@@ -42,7 +42,8 @@ def probe(vr, r, n, bpv, reps=3):
     elems = ((n + 7) // 8) ** 3 * 512
     sizes = {"quad_xy": elems * 4 * bpv, "quad_xz": elems * 4 * bpv, "quad_yz": elems * 4 * bpv, "run_z": ((n + 7) // 8) ** 3 * 2304,
              "run_y": ((n + 7) // 8) ** 3 * 2304, "voxel": elems * bpv, "oct": elems * 8 * bpv,
-             "col_x": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_y": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_z": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256}
+             "col_x": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_y": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256, "col_z": ((n + 3) // 4) ** 2 * ((n + 2) // 3) * 256,
+             "colv_x": ((n + 3) // 4) ** 2 * ((n + 15) // 16) * 256, "colv_y": ((n + 3) // 4) ** 2 * ((n + 15) // 16) * 256, "colv_z": ((n + 3) // 4) ** 2 * ((n + 15) // 16) * 256}
     out["rooflines"] = {}
     for name, ms in out["copies"].items():
         best = min(ms)
