@@ -70,6 +70,22 @@ struct RayKernelArgs {
 	uint32_t dual_shift;               // ... one bit per group of (1 << dual_shift) consecutive tile NUMBERS (>= 6: 64 numbers = one 8x8-tile block of the numbering)
 	uint32_t dual_bits[32];            // ... bit set = the block's tiles read the copy with runs along y (vr_hip_api.cpp dual_choice_bits)
 	uint32_t col_axis;                 // kLayoutColumn: the march axis m (0 x, 1 y, 2 z) of the window copy handed to the kernel
+	// kLayoutColumn: what the DENSE path of the column kernels reads back from the kernel-argument segment (it cannot keep these ~25 scalars
+	// live across the march), grouped so that ONE scalar load fetches everything a step of that path needs: the path is a dependent chain
+	// per wave, and every separate s_load + s_waitcnt on it is a scalar-cache round trip (seven of them per shaded sample before the grouping)
+	struct ColDenseSample {            // every composited sample
+		float ax, ay, az;              // direction * half (the texel-space direction A of coordinate = fma(k, A, B)), the device's own fp32 products
+		float tf_scale;
+		float max_x, max_y, max_z;
+		float tf_zero_below;
+		float light_kd, ray_threshold;
+		uint32_t pad[2];
+	} col_sample;
+	struct ColDenseShade {             // samples that are shaded
+		float dir[3];  float kd_scaled;
+		float light[3]; uint32_t nbu;  // lateral blocks along u (col_blocks(dim_u))
+		float lh[3];   uint32_t nw;    // windows per column (col_windows(dim_m))
+	} col_shade;
 #ifdef VR_BOUNDS_CHECK
 	// `make EXTRA=-DVR_BOUNDS_CHECK` (debug build, not the product): every gather address of the march is held against the array it must
 	// lie in, every address-table index against its padded table, the tile-cost slot against its buffer; the first violation is recorded

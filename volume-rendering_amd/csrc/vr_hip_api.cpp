@@ -35,6 +35,7 @@ struct EventPair { hipEvent_t start = nullptr, stop = nullptr; bool pending = fa
 struct vr_ctx {
 	int device = -1;
 	hipStream_t stream = nullptr;           // context-owned stream for the synchronous entry points
+	hipStream_t stream_first = nullptr;     // vr_hip_render: the first row slice of a frame runs here, AHEAD of the rest (highest stream priority)
 	// window
 	uint32_t win_w = 0, win_h = 0;
 	void *fb = nullptr; size_t fb_bytes = 0;
@@ -68,7 +69,7 @@ struct vr_ctx {
 	                  uint32_t *cost = nullptr, *order = nullptr; uint32_t capacity = 0, order_tiles = 0;
 	                  uint32_t dual_state = 0;
 	                  hipEvent_t order_ready = nullptr; hipStream_t order_stream = nullptr; };
-	MapEntry map_cache[16]; uint32_t map_cached = 0, map_next = 0;
+	MapEntry map_cache[32]; uint32_t map_cached = 0, map_next = 0;      // (8 benchmark views x the two row slices of vr_hip_render, and the whole frames beside them)
 	// Measured-cost launch orders (vr_kernels.hip tile_order_kernel), keyed by what the cost of a tile DEPENDS on — sampling mode,
 	// leaping / termination on or off, projection, the view's major axis, the band partition, the tile grid and the copy read — not by
 	// the byte image of the parameters: a camera that moves keeps its entry, every frame launches its tiles in the order the most recent
@@ -81,7 +82,7 @@ struct vr_ctx {
 	struct OrderKey { int32_t direction_q[3]; uint32_t sampling, esl, ert, perspective, major_axis, layout, view_w, view_h, x0, out_width, out_rows, band_rows, band_stride, band_first,
 	                  dim[3], tiles_x, tiles_y; };
 	struct OrderEntry { OrderKey key; bool used = false; SchedSlot slot[3]; vr_params last; bool has_last = false; uint32_t repeats = 0; uint64_t lru = 0; };
-	OrderEntry order_cache[16];
+	OrderEntry order_cache[32];
 	uint64_t seq_next = 1, completed_seq = 0;      // frames launched so far + 1; every frame <= completed_seq is known to have finished
 	uint64_t ring_seq[kEventRing] = {};            // the frame whose events sit in ring entry i
 	uint32_t tile_scheduling = 1;           // vr_hip_set_tile_scheduling: 0 = tile = workgroup id, 1 = measured-cost order, 2 = cost map
@@ -478,8 +479,9 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			// in flight on other streams — the validator is a testing aid, so it simply waits for them
 			if (hit->dual_state != 0 || hit->order_tiles != 0) VR_TRY(c, drain(c));
 			hit->dual_state = 0; hit->order_tiles = 0;
-			c->map_next = (c->map_next + 1) % 16u;
-			if (c->map_cached < 16u) c->map_cached++;
+			constexpr uint32_t kMaps = sizeof c->map_cache / sizeof c->map_cache[0];
+			c->map_next = (c->map_next + 1) % kMaps;
+			if (c->map_cached < kMaps) c->map_cached++;
 			hit->p = *p; memcpy(hit->dim, c->dim, sizeof c->dim);
 			hit->lane_map = a.lane_map; hit->phase_x = a.phase_x; hit->phase_y = a.phase_y;
 		}
@@ -534,6 +536,17 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			for (int i = 0; i < 3; i++) if (i != m && d[i] * 4.0f >= 0.45f) take = false;
 		if (take && copy_possible(c, (p->sampling == VR_SAMPLE_NEAREST ? kCopyColVoxX : kCopyColX) + (uint32_t) m)) {
 			a.layout = kLayoutColumn; a.col_axis = (uint32_t) m; a.brick_plane = (uint32_t) m;
+			// the dense path's constants, grouped for one scalar load each (vr_device.h); the products are the device's own fp32 products
+			const bool nearest = p->sampling == VR_SAMPLE_NEAREST;
+			a.col_sample.ax = p->view.direction[0] * a.half_x; a.col_sample.ay = p->view.direction[1] * a.half_y; a.col_sample.az = p->view.direction[2] * a.half_z;
+			a.col_sample.tf_scale = a.tf_scale; a.col_sample.tf_zero_below = a.tf_zero_below;
+			a.col_sample.max_x = a.max_x; a.col_sample.max_y = a.max_y; a.col_sample.max_z = a.max_z;
+			a.col_sample.light_kd = p->light_kd; a.col_sample.ray_threshold = p->ray_threshold;
+			for (int i = 0; i < 3; i++) { a.col_shade.dir[i] = p->view.direction[i]; a.col_shade.light[i] = p->view.light_pos[i]; }
+			a.col_shade.lh[0] = a.lh_x; a.col_shade.lh[1] = a.lh_y; a.col_shade.lh[2] = a.lh_z;
+			a.col_shade.kd_scaled = a.kd_scaled;
+			a.col_shade.nbu = col_blocks(c->dim[m == 0 ? 1 : 0]);
+			a.col_shade.nw = col_windows(c->dim[m], nearest ? kColVoxCells : kColCells);
 			dual_analytic = false; dual_stage = -1;
 		}
 	}
@@ -894,6 +907,11 @@ int vr_hip_create(int device, vr_ctx **out) {
 	*out = c;                                    // handed out even on failure below so last_error stays readable
 	VR_TRY(c, hipSetDevice(device));
 	VR_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	{
+		int least = 0, greatest = 0;
+		VR_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+		VR_TRY(c, hipStreamCreateWithPriority(&c->stream_first, hipStreamNonBlocking, greatest));
+	}
 	VR_TRY(c, hipMalloc((void **) &c->tf, VR_TF_SIZE * 4 * sizeof(float)));
 	VR_TRY(c, hipMalloc((void **) &c->esl, VR_ESL_VOLUME_SIZE * sizeof(uint32_t)));
 	VR_TRY(c, hipMalloc((void **) &c->minmax, 32 * 32 * 32 * 2));
@@ -930,6 +948,7 @@ void vr_hip_destroy(vr_ctx *c) {
 	free_bricks(c);
 	if (c->minmax) (void) hipFree(c->minmax);
 	if (c->hist) (void) hipFree(c->hist);
+	if (c->stream_first) { (void) hipStreamSynchronize(c->stream_first); (void) hipStreamDestroy(c->stream_first); }
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1112,10 +1131,34 @@ int vr_hip_render(vr_ctx *c, const vr_params *p, uint8_t *host_rgba) {
 		return fail(c, VR_ERR_NOT_READY, "output larger than the window buffer: call vr_hip_set_window first");
 	VR_TRY(c, hipSetDevice(c->device));
 	const auto t0 = std::chrono::steady_clock::now();
-	rc = launch_frame(c, p, c->fb, c->stream);
-	if (rc) return rc;
-	VR_TRY(c, hipMemcpyAsync(host_rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->stream));
-	VR_TRY(c, hipStreamSynchronize(c->stream));
+	// The reference's timed region ends with the frame in HOST memory (GPURenderer1.cu:107-110).  A frame of unpartitioned rows is
+	// rendered as TWO row slices: the first on a stream of the highest priority, so that its workgroups are dispatched ahead of the
+	// second slice's and it finishes about halfway through the frame; its copy to the host then runs while the second slice still
+	// renders, and only the second half of the PCIe transfer is left behind the kernels (measured on the prototype,
+	// scripts/host_slices_probe.py, C4: 2.32 ms per frame against 2.48 as one launch + one copy, the kernel alone 2.28 wall).  The
+	// pixels are the same: a slice is a band partition (x0 / band fields of vr_params), the partition the multi-GPU path renders.
+	static const int host_slices = [] { const char *e = getenv("VR_HOST_SLICES"); return e ? atoi(e) : 2; }();         // VR_HOST_SLICES=1: one launch + one copy (A/B)
+	const uint32_t first_rows = ((p->out_rows + 1u) / 2u + 15u) & ~15u;      // whole workgroup tiles (32x16 pixels)
+	if (host_slices >= 2 && p->band_stride == 1 && p->band_first == 0 && first_rows < p->out_rows && bytes >= (1u << 20)) {
+		vr_params q = *p;
+		q.band_rows = first_rows; q.band_stride = 2;                        // gy = band_first * first_rows + ly for ly < first_rows
+		q.band_first = 0; q.out_rows = first_rows;
+		rc = launch_frame(c, &q, c->fb, c->stream_first);
+		if (rc) return rc;
+		const size_t first_bytes = (size_t) first_rows * p->out_width * 4;
+		q.band_first = 1; q.out_rows = p->out_rows - first_rows;
+		rc = launch_frame(c, &q, (uint8_t *) c->fb + first_bytes, c->stream);
+		if (rc) { (void) hipStreamSynchronize(c->stream_first); return rc; }
+		VR_TRY(c, hipMemcpyAsync(host_rgba, c->fb, first_bytes, hipMemcpyDeviceToHost, c->stream_first));
+		VR_TRY(c, hipMemcpyAsync(host_rgba + first_bytes, (uint8_t *) c->fb + first_bytes, bytes - first_bytes, hipMemcpyDeviceToHost, c->stream));
+		VR_TRY(c, hipStreamSynchronize(c->stream_first));
+		VR_TRY(c, hipStreamSynchronize(c->stream));
+	} else {
+		rc = launch_frame(c, p, c->fb, c->stream);
+		if (rc) return rc;
+		VR_TRY(c, hipMemcpyAsync(host_rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->stream));
+		VR_TRY(c, hipStreamSynchronize(c->stream));
+	}
 	const auto t1 = std::chrono::steady_clock::now();
 	c->last_total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
 	if (c->last_total_ms > c->total_ms_max) c->total_ms_max = c->last_total_ms;

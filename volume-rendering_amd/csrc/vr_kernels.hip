@@ -18,6 +18,7 @@
 // expression by expression (IEEE divide / sqrt, no fused ops), so its output is bit-identical to the reference's CPU
 // renderer.  TRILINEAR mode is defined with explicit fused multiply-adds (oracle/vr_oracle.c states the same sequence).
 #include "vr_device.h"
+#include <initializer_list>
 
 namespace vr {
 
@@ -567,6 +568,9 @@ __device__ __forceinline__ void tile_to_xy(uint32_t tiles_x, uint32_t tiles_y, u
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 __device__ __forceinline__ float rlane(float v, int lane) { return __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(v), lane)); }
+// the values must be in scalar registers HERE: scalar loads that produce them are issued together before this point and waited for once
+template <typename T> __device__ __forceinline__ void hold_scalar(const T &v) { asm volatile("" :: "s"(v)); }
+template <typename... T> __device__ __forceinline__ void hold_scalars(const T &...v) { (void) std::initializer_list<int>{ (hold_scalar(v), 0)... }; }
 
 // ---- the ray-march kernel ------------------------------------------------------------------------------------------
 
@@ -1120,6 +1124,9 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #define VR_COL_DEPTH 3
 #endif
 constexpr int kColDepth = VR_COL_DEPTH, kColSlots = kColDepth + 1;
+#ifndef VR_COL_ISSUE_LATE
+#define VR_COL_ISSUE_LATE 0            // 1: the next window's gather is issued behind a dense window's samples (measured: 1.72 / 1.78 / 2.25 ms against 1.70 / 1.75 / 2.23)
+#endif
 
 __device__ __forceinline__ void managed_load128_s(u32x4 &dst, uint32_t byte_offset, uint64_t base) {     // window gather: scalar base + per-lane offset
 	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_offset), "s"(base));
@@ -1158,6 +1165,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	constexpr int U = M == 0 ? 1 : 0, V = M == 2 ? 1 : 2;
 	typedef const RayKernelArgs __attribute__((address_space(4))) *ConstArgs;
 	__shared__ f4 tf_l[VR_TF_SIZE + 1], dtf_l[VR_TF_SIZE + 1];
+	__shared__ f4 org_l[512];                                           // every thread's ray origin (see origin_again)
 	{
 		const uint32_t t = threadIdx.x;
 		if (t <= VR_TF_SIZE) {
@@ -1191,14 +1199,17 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	// -- View::get_ray (ViewBase.h:23-35), orthogonal branch only (the host never launches this kernel for a perspective view)
 	bool alive = in_frame && gx < a.p.view.width && gy < a.p.view.height;
 	const f3 dir = ld3(a.p.view.direction);
-	// (the march keeps the frame pixel in ONE register and forms the ray origin again for the few samples that are shaded: two registers less)
-	uint32_t pixel = (gy << 16) | (gx & 0xffffu);
-	auto origin_of = [](ConstArgs q, uint32_t px) {
-		const float fx = (float) ((int) (px & 0xffffu) - (int) (q->p.view.width / 2u)), fy = (float) ((int) (px >> 16) - (int) (q->p.view.height / 2u));
-		f3 o = mk3(q->p.view.origin[0] + q->p.view.right_plane[0] * fx, q->p.view.origin[1] + q->p.view.right_plane[1] * fx, q->p.view.origin[2] + q->p.view.right_plane[2] * fx);
-		return mk3(o.x + q->p.view.up_plane[0] * fy, o.y + q->p.view.up_plane[1] * fy, o.z + q->p.view.up_plane[2] * fy);
-	};
-	const f3 origin = origin_of((ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(), pixel);
+	// (the march does not keep the ray origin in three registers: the samples that are shaded — the dense path is bound by its vector
+	// instructions — read it back from the thread's own LDS slot, one ds_read_b128; `org_slot` is the slot's byte offset)
+	f3 origin;
+	{
+		const float fx = (float) ((int) gx - (int) (a.p.view.width / 2u)), fy = (float) ((int) gy - (int) (a.p.view.height / 2u));
+		const f3 o = mk3(a.p.view.origin[0] + a.p.view.right_plane[0] * fx, a.p.view.origin[1] + a.p.view.right_plane[1] * fx, a.p.view.origin[2] + a.p.view.right_plane[2] * fx);
+		origin = mk3(o.x + a.p.view.up_plane[0] * fy, o.y + a.p.view.up_plane[1] * fy, o.z + a.p.view.up_plane[2] * fy);
+	}
+	uint32_t org_slot = threadIdx.x * (uint32_t) sizeof(f4);
+	{ f4 o4; o4.x = origin.x; o4.y = origin.y; o4.z = origin.z; o4.w = 0.0f; org_l[threadIdx.x] = o4; }      // read by this thread only: no barrier
+	auto origin_again = [&]() { pin(org_slot); const f4 o4 = *(const f4 *) ((const char *) org_l + org_slot); return mk3(o4.x, o4.y, o4.z); };
 	float kx = 0, ky = 0;
 	alive = alive && intersect(origin, dir, kx, ky);
 	const float step = a.p.ray_step;
@@ -1234,27 +1245,24 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	struct KernelArguments { RayKernelArgs a; const uint8_t *copy; const float *tf_g; uint32_t *out; };      // the kernel's parameter list as it lies in that segment
 	typedef const KernelArguments __attribute__((address_space(4))) *ConstKernelArguments;
 	// explicit fetch of the element pair (march index i, i + 1) of a texel-space position, clamp addressing: any position is in bounds
-	auto pair_address = [&](ConstArgs q, float xb, float yb, float zb) {
-		const int ix = (int) __builtin_amdgcn_fmed3f(xb, 0.0f, q->max_x), iy = (int) __builtin_amdgcn_fmed3f(yb, 0.0f, q->max_y), iz = (int) __builtin_amdgcn_fmed3f(zb, 0.0f, q->max_z);
+	auto pair_address = [&](const uint8_t *copy_p, float mx, float my, float mz, uint32_t blocks_u, uint32_t windows, float xb, float yb, float zb) {
+		const int ix = (int) __builtin_amdgcn_fmed3f(xb, 0.0f, mx), iy = (int) __builtin_amdgcn_fmed3f(yb, 0.0f, my), iz = (int) __builtin_amdgcn_fmed3f(zb, 0.0f, mz);
 		const uint32_t iu = (uint32_t) (U == 0 ? ix : iy), iv = (uint32_t) (V == 1 ? iy : iz), im = (uint32_t) (M == 0 ? ix : (M == 1 ? iy : iz));
 		const uint32_t wq = __umulhi(im, 0xAAAAAAABu) >> 1, sub = im - wq * 3u;
-		const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
-		const uint32_t block = ((iv >> kColEdgeLog2) * col_blocks(qdim_u) + (iu >> kColEdgeLog2)) * col_windows(qdim_m) + wq;
-		const uint8_t *p = ((ConstKernelArguments) q)->copy + ((uint64_t) block * kColBlockBytes + (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + sub * 4u);
+		const uint32_t block = ((iv >> kColEdgeLog2) * blocks_u + (iu >> kColEdgeLog2)) * windows + wq;
+		const uint32_t in_block = (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + sub * 4u;      // < 256: summed in 32 bits
+		const uint8_t *p = copy_p + ((uint64_t) block * kColBlockBytes + in_block);
 		return VR_BC_POINTER(a, const uint8_t *, p, 8u);
 	};
-	auto fetch_pair = [&](ConstArgs q, float xb, float yb, float zb, uint32_t &w0, uint32_t &w1) {
-		const uint2 both = *(const uint2 *) pair_address(q, xb, yb, zb);
-		w0 = both.x; w1 = both.y;
-	};
-	auto coords = [&](ConstArgs q, float kk, float &xb, float &yb, float &zb) {          // fma(k, A, B) with A = direction * N/2 (the same product, bit for bit)
-		xb = VR_FMA(kk, q->p.view.direction[0] * q->half_x, B.x); yb = VR_FMA(kk, q->p.view.direction[1] * q->half_y, B.y); zb = VR_FMA(kk, q->p.view.direction[2] * q->half_z, B.z);
+	auto coords = [&](ConstArgs q, float kk, float &xb, float &yb, float &zb) {          // fma(k, A, B) with A = direction * N/2 (col_sample: the same fp32 products, formed by the host)
+		xb = VR_FMA(kk, q->col_sample.ax, B.x); yb = VR_FMA(kk, q->col_sample.ay, B.y); zb = VR_FMA(kk, q->col_sample.az, B.z);
 	};
 	auto fetch_at = [&](float kk, uint32_t &w0, uint32_t &w1) {                           // the element pair of the sample at kk, from each lane's true column
 		ConstArgs q = dense_args();
 		float xb, yb, zb;
 		coords(q, kk, xb, yb, zb);
-		fetch_pair(q, xb, yb, zb, w0, w1);
+		const uint2 both = *(const uint2 *) pair_address(((ConstKernelArguments) q)->copy, q->col_sample.max_x, q->col_sample.max_y, q->col_sample.max_z, q->col_shade.nbu, q->col_shade.nw, xb, yb, zb);
+		w0 = both.x; w1 = both.y;
 	};
 	// the same as a MANAGED gather (the compiler does not see it: a load it knows to be in flight across the window loop's back edge makes
 	// it put s_waitcnt vmcnt(0) in front of every window gather, and the prefetch pipeline is gone): wait with managed_wait<0>() before use
@@ -1262,18 +1270,24 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 		ConstArgs q = dense_args();
 		float xb, yb, zb;
 		coords(q, kk, xb, yb, zb);
-		managed_load64(both, (uint64_t) (uintptr_t) pair_address(q, xb, yb, zb));
+		managed_load64(both, (uint64_t) (uintptr_t) pair_address(((ConstKernelArguments) q)->copy, q->col_sample.max_x, q->col_sample.max_y, q->col_sample.max_z, q->col_shade.nbu, q->col_shade.nw, xb, yb, zb));
 	};
 	// one sample at `k` whose element pair is (w0, w1): the general kernel's body from the transparency test on
 	auto sample = [&](uint32_t w0, uint32_t w1) {
 		if ((__builtin_amdgcn_uicmp((w0 | w1) & a.skip_mask, a.skip_cmp, kIcmpNE) & live) != 0ull && VR_OPEN_LANES(acc.w, live) != 0ull) {
 			ConstArgs q = dense_args();
+			// everything this sample needs from the argument segment in ONE scalar load (held: the compiler would otherwise load each value
+			// where it is first used, one scalar-cache round trip after the other on a path that is a dependent chain)
+			RayKernelArgs::ColDenseSample ds;
+			ds.ax = q->col_sample.ax; ds.ay = q->col_sample.ay; ds.az = q->col_sample.az; ds.tf_scale = q->col_sample.tf_scale;
+			ds.max_x = q->col_sample.max_x; ds.max_y = q->col_sample.max_y; ds.max_z = q->col_sample.max_z; ds.tf_zero_below = q->col_sample.tf_zero_below;
+			ds.light_kd = q->col_sample.light_kd; ds.ray_threshold = q->col_sample.ray_threshold;
+			hold_scalars(ds.ax, ds.ay, ds.az, ds.tf_scale, ds.max_x, ds.max_y, ds.max_z, ds.tf_zero_below, ds.light_kd, ds.ray_threshold);
 			live &= __builtin_amdgcn_fcmpf(k, ky, kFcmpOLE);                                              // the sample's own segment test
-			float xb, yb, zb;
-			coords(q, k, xb, yb, zb);
-			const float raw = col_resolve<M, kQ8>(w0, w1, q->max_x, q->max_y, q->max_z, xb, yb, zb);     // GPURenderer4.cu:76
-			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, q->tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
-			if ((__builtin_amdgcn_fcmpf(tb, q->tf_zero_below, kFcmpOGE) & live) != 0ull) {
+			const float xb = VR_FMA(k, ds.ax, B.x), yb = VR_FMA(k, ds.ay, B.y), zb = VR_FMA(k, ds.az, B.z);
+			const float raw = col_resolve<M, kQ8>(w0, w1, ds.max_x, ds.max_y, ds.max_z, xb, yb, zb);     // GPURenderer4.cu:76
+			const float tb = __builtin_amdgcn_fmed3f(VR_FMA(raw, ds.tf_scale, -0.5f), 0.0f, (float) (VR_TF_SIZE - 1));
+			if ((__builtin_amdgcn_fcmpf(tb, ds.tf_zero_below, kFcmpOGE) & live) != 0ull) {
 				f4 c;
 				{
 					const uint32_t i = (uint32_t) (int) tb;
@@ -1281,23 +1295,32 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 					const f4 c0 = tf_l[i], dc = dtf_l[i];
 					c.x = VR_FMA(w, dc.x, c0.x); c.y = VR_FMA(w, dc.y, c0.y); c.z = VR_FMA(w, dc.z, c0.z); c.w = VR_FMA(w, dc.w, c0.w);
 				}
-				const uint64_t shaded = q->p.light_kd > 0.01f ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
+				const uint64_t shaded = ds.light_kd > 0.01f ? (__builtin_amdgcn_fcmpf(c.w, 0.05f, kFcmpOGT) & live) : 0ull;   // GPURenderer4.cu:78
 				if (shaded != 0ull) {                                                                  // GPURenderer4.cu:41-51 shade_texture
-					const f3 qdir = mk3(q->p.view.direction[0], q->p.view.direction[1], q->p.view.direction[2]);
-					pin(pixel);
-					const f3 p3 = march_point<SAMPLING>(origin_of(q, pixel), qdir, k);
-					const f3 d = mk3(q->p.view.light_pos[0] - p3.x, q->p.view.light_pos[1] - p3.y, q->p.view.light_pos[2] - p3.z);
+					const f3 org = origin_again();                                                     // (its LDS read is in flight with the scalar load below)
+					RayKernelArgs::ColDenseShade dh;                                                   // (one scalar load again)
+					for (int i = 0; i < 3; i++) { dh.dir[i] = q->col_shade.dir[i]; dh.light[i] = q->col_shade.light[i]; dh.lh[i] = q->col_shade.lh[i]; }
+					dh.kd_scaled = q->col_shade.kd_scaled; dh.nbu = q->col_shade.nbu; dh.nw = q->col_shade.nw;
+					const uint8_t *const copy_p = ((ConstKernelArguments) q)->copy;
+					hold_scalars(dh.dir[0], dh.dir[1], dh.dir[2], dh.kd_scaled, dh.light[0], dh.light[1], dh.light[2], dh.lh[0], dh.lh[1], dh.lh[2]);
+					hold_scalars(dh.nbu, dh.nw, (uint64_t) (uintptr_t) copy_p);
+					const f3 p3 = march_point<SAMPLING>(org, mk3(dh.dir[0], dh.dir[1], dh.dir[2]), k);
+					const f3 d = mk3(dh.light[0] - p3.x, dh.light[1] - p3.y, dh.light[2] - p3.z);
 					const float inv = rsqrt_nr(VR_FMA(d.z, d.z, VR_FMA(d.y, d.y, d.x * d.x)));
-					const float sx = VR_FMA(d.x * inv, q->lh_x, xb), sy = VR_FMA(d.y * inv, q->lh_y, yb), sz = VR_FMA(d.z * inv, q->lh_z, zb);
+					const float sx = VR_FMA(d.x * inv, dh.lh[0], xb), sy = VR_FMA(d.y * inv, dh.lh[1], yb), sz = VR_FMA(d.z * inv, dh.lh[2], zb);
 					uint32_t l0, l1;
-					fetch_pair(q, sx, sy, sz, l0, l1);
-					const float raw_l = col_resolve<M, kQ8>(l0, l1, q->max_x, q->max_y, q->max_z, sx, sy, sz);
-					const float diffuse = select_lanes(shaded, (raw_l - raw) * q->kd_scaled);
+#ifdef VR_COL_EXP_NO_SHADE_FETCH      // timing-only experiment: the shading sample costs no memory round trip
+					l0 = w0 ^ (uint32_t) (int) sx; l1 = w1 ^ (uint32_t) (int) sy;
+#else
+					{ const uint2 both = *(const uint2 *) pair_address(copy_p, ds.max_x, ds.max_y, ds.max_z, dh.nbu, dh.nw, sx, sy, sz); l0 = both.x; l1 = both.y; }
+#endif
+					const float raw_l = col_resolve<M, kQ8>(l0, l1, ds.max_x, ds.max_y, ds.max_z, sx, sy, sz);
+					const float diffuse = select_lanes(shaded, (raw_l - raw) * dh.kd_scaled);
 					c.x += diffuse; c.y += diffuse; c.z += diffuse;
 				}
 				const float t = select_lanes(live, 1 - acc.w);
 				acc.x = VR_FMA(c.x, t, acc.x); acc.y = VR_FMA(c.y, t, acc.y); acc.z = VR_FMA(c.z, t, acc.z); acc.w = VR_FMA(c.w, t, acc.w);
-				live &= ~__builtin_amdgcn_fcmpf(acc.w, q->p.ray_threshold, kFcmpOGT);                  // ERT (CPURenderer.cpp:35-36)
+				live &= ~__builtin_amdgcn_fcmpf(acc.w, ds.ray_threshold, kFcmpOGT);                    // ERT (CPURenderer.cpp:35-36)
 			}
 		}
 	};
@@ -1483,14 +1506,17 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 			static_for<0, kColDepth>([&](auto j) { issue(slot[j.value]); });
 			auto window_step = [&](auto jc) {
 				constexpr int c = decltype(jc)::value, n = (c + kColDepth) % kColSlots;
-				issue(slot[n]);
+				// (VR_COL_ISSUE_LATE, an experiment kept as a switch: the gather of the window kColDepth ahead issued AFTER this window's samples when
+				// the window is dense — the shading fetch of a composited sample returns behind every gather issued before it, and one issued
+				// just now is a whole HBM round trip away.  Not faster: the transparent windows behind a dense region then wait for their data.)
+				if (!VR_COL_ISSUE_LATE) issue(slot[n]);
 				__builtin_amdgcn_sched_barrier(0);
-				pin(slot[c]); managed_wait<kColDepth>(); pin(slot[c]);
+				pin(slot[c]); managed_wait<(VR_COL_ISSUE_LATE ? kColDepth - 1 : kColDepth)>(); pin(slot[c]);
 				const u32x4 o = slot[c];
 				if (c == 0) live &= __builtin_amdgcn_fcmpf(rlane(kvec, pos), ky, kFcmpOLE);      // lazy exit test: once per rotation of the slots (and by every sample that composites)
 				bool careful = false;                                       // an event window: some lane changes its column somewhere inside
 				if (kFlips) {
-					const int key = issue_key - (kColDepth + 1);               // = dsign * cur: the issue frontier is kColDepth windows ahead and has just moved on
+					const int key = issue_key - (kColDepth + (VR_COL_ISSUE_LATE ? 0 : 1));               // = dsign * cur: the issue frontier is kColDepth windows ahead
 					while (key > cons_event) { cons_at++; cons_event = __builtin_amdgcn_readlane(events, cons_at & 63); }
 					careful = key == cons_event;
 				}
@@ -1500,6 +1526,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 				if ((__builtin_amdgcn_uicmp(all4, a.skip_cmp, kIcmpNE) & live) != 0ull) dense = dense || VR_OPEN_LANES(acc.w, live) != 0ull;
 #endif
 				if (!dense) {
+					if (VR_COL_ISSUE_LATE) issue(slot[n]);
 					// a transparent window: its samples — consecutive lanes of the batch, from pos — just pass.  A window holds at most 3 * 64 + 1
 					// samples (a sample advances >= 1/64 cell, checked above), i.e. it ends within four batches: the bound is a hang guard
 					for (int batches = 0; batches < 5; batches++) {
@@ -1533,6 +1560,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 						refill(); pos = 0;
 					}
 					pos = pos < 64 ? pos : 63;
+					if (VR_COL_ISSUE_LATE) issue(slot[n]);
 				}
 				cur += dsign;
 			};
@@ -1576,6 +1604,7 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 	typedef const RayKernelArgs __attribute__((address_space(4))) *ConstArgs;
 	__shared__ f4 tf_l[VR_TF_SIZE];
 	__shared__ float unit_l[256];                                       // unit[s] = (float) s / 255.0f, the quotient Raycaster::shade forms twice per shaded sample
+	__shared__ f4 org_l[512];                                           // every thread's ray origin
 	{
 		const uint32_t t = threadIdx.x;
 		if (t < VR_TF_SIZE) tf_l[t] = ((const f4 *) tf_g)[t];
@@ -1599,13 +1628,15 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 
 	bool alive = in_frame && gx < a.p.view.width && gy < a.p.view.height;
 	const f3 dir = ld3(a.p.view.direction);
-	uint32_t pixel = (gy << 16) | (gx & 0xffffu);
-	auto origin_of = [](ConstArgs q, uint32_t px) {
-		const float fx = (float) ((int) (px & 0xffffu) - (int) (q->p.view.width / 2u)), fy = (float) ((int) (px >> 16) - (int) (q->p.view.height / 2u));
-		f3 o = mk3(q->p.view.origin[0] + q->p.view.right_plane[0] * fx, q->p.view.origin[1] + q->p.view.right_plane[1] * fx, q->p.view.origin[2] + q->p.view.right_plane[2] * fx);
-		return mk3(o.x + q->p.view.up_plane[0] * fy, o.y + q->p.view.up_plane[1] * fy, o.z + q->p.view.up_plane[2] * fy);
-	};
-	const f3 origin = origin_of((ConstArgs) __builtin_amdgcn_kernarg_segment_ptr(), pixel);
+	f3 origin;                                                          // kept in the thread's LDS slot for the samples that are shaded (see colmarch_kernel)
+	{
+		const float fx = (float) ((int) gx - (int) (a.p.view.width / 2u)), fy = (float) ((int) gy - (int) (a.p.view.height / 2u));
+		const f3 o = mk3(a.p.view.origin[0] + a.p.view.right_plane[0] * fx, a.p.view.origin[1] + a.p.view.right_plane[1] * fx, a.p.view.origin[2] + a.p.view.right_plane[2] * fx);
+		origin = mk3(o.x + a.p.view.up_plane[0] * fy, o.y + a.p.view.up_plane[1] * fy, o.z + a.p.view.up_plane[2] * fy);
+	}
+	uint32_t org_slot = threadIdx.x * (uint32_t) sizeof(f4);
+	{ f4 o4; o4.x = origin.x; o4.y = origin.y; o4.z = origin.z; o4.w = 0.0f; org_l[threadIdx.x] = o4; }
+	auto origin_again = [&]() { pin(org_slot); const f4 o4 = *(const f4 *) ((const char *) org_l + org_slot); return mk3(o4.x, o4.y, o4.z); };
 	float kx = 0, ky = 0;
 	alive = alive && intersect(origin, dir, kx, ky);
 	const float step = a.p.ray_step;
@@ -1643,11 +1674,12 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 		const uint32_t iu = U == 0 ? ix : iy, iv = V == 1 ? iy : iz, im = M == 0 ? ix : (M == 1 ? iy : iz);
 		const uint32_t qdim_u = U == 0 ? q->dim_x : q->dim_y, qdim_m = M == 0 ? q->dim_x : (M == 1 ? q->dim_y : q->dim_z);
 		const uint32_t block = ((iv >> kColEdgeLog2) * col_blocks(qdim_u) + (iu >> kColEdgeLog2)) * col_windows(qdim_m, kColVoxCells) + (im >> 4);
-		const uint8_t *p = ((ConstKernelArguments) q)->copy + ((uint64_t) block * kColBlockBytes + (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + (im & 15u));
+		const uint32_t in_block = (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + (im & 15u);      // < 256: summed in 32 bits
+		const uint8_t *p = ((ConstKernelArguments) q)->copy + ((uint64_t) block * kColBlockBytes + in_block);
 		return VR_BC_POINTER(a, const uint8_t *, p, 1u);
 	};
 	auto position = [&](ConstArgs q, float kk) {                         // CPURenderer.cpp:17,24,38: origin + direction * k, two roundings per axis
-		const f3 o = origin_of(q, pixel);
+		const f3 o = origin_again();
 		return mk3(o.x + q->p.view.direction[0] * kk, o.y + q->p.view.direction[1] * kk, o.z + q->p.view.direction[2] * kk);
 	};
 	// one sample at `k` whose voxel is s: the general kernel's NEAREST body from the transparency test on (CPURenderer.cpp:29-39)
@@ -1661,7 +1693,6 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 			const float kd = q->p.light_kd;
 			const uint64_t shaded = kd > 0.01f ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
 			if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
-				pin(pixel);
 				const f3 pt = position(q, k);
 				const f3 d = mk3(q->p.view.light_pos[0] - pt.x, q->p.view.light_pos[1] - pt.y, q->p.view.light_pos[2] - pt.z);
 				const float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
