@@ -85,6 +85,7 @@ struct RayKernelArgs {
 		float dir[3];  float kd_scaled;
 		float light[3]; uint32_t nbu;  // lateral blocks along u (col_blocks(dim_u))
 		float lh[3];   uint32_t nw;    // windows per column (col_windows(dim_m))
+		uint32_t dim[3], pad;          // Model::dims (colmarch_nearest_kernel: map_float_int of the shading position)
 	} col_shade;
 #ifdef VR_BOUNDS_CHECK
 	// `make EXTRA=-DVR_BOUNDS_CHECK` (debug build, not the product): every gather address of the march is held against the array it must
@@ -97,18 +98,24 @@ struct RayKernelArgs {
 	uint32_t bc_ntiles;
 #endif
 };
-// Tiles are numbered in VR_TILE_ORDER x VR_TILE_ORDER blocks (blocks row-major, tiles row-major inside a block, the ragged right /
-// bottom margins after them): consecutive workgroups — which the hardware spreads over the eight XCDs — are screen neighbours.
+// Tiles are numbered in VR_TILE_ORDER x VR_TILE_ORDER blocks (blocks row-major, tiles column by column inside a block — VR_XCD_MODE
+// below —, the ragged right / bottom margins after them): consecutive workgroups — which the hardware spreads over the eight XCDs — are screen neighbours.
 #ifndef VR_TILE_ORDER
 #define VR_TILE_ORDER 8
 #endif
-// tile number -> tile column / row; what raymarch_kernel computes (without its experiment switches), for the host (cost map)
+// Which tiles of an 8x8-tile block share an XCD (vr_kernels.hip tile_to_xy, measurements there): 5 = the tiles of a block are numbered
+// column by column, so that in workgroup order XCD x renders ROW x of every block.
+#ifndef VR_XCD_MODE
+#define VR_XCD_MODE 5
+#endif
+// tile number -> tile column / row; what raymarch_kernel computes (without its other experiment switches), for the host (cost map)
 inline void tile_number_to_xy(uint32_t tile, uint32_t tiles_x, uint32_t tiles_y, uint32_t *x, uint32_t *y) {
 	constexpr uint32_t B = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
 	const uint32_t full_cols = tiles_x / B, full_rows = tiles_y / B, nblocked = full_cols * full_rows * B * B;
 	if (tile < nblocked) {
 		const uint32_t blk = tile / (B * B), in = tile - blk * (B * B), by = blk / full_cols, bx = blk - by * full_cols;
-		*x = bx * B + in % B; *y = by * B + in / B;
+		if (B == 8 && VR_XCD_MODE == 5) { *x = bx * B + in / B; *y = by * B + in % B; }
+		else { *x = bx * B + in % B; *y = by * B + in / B; }
 		return;
 	}
 	uint32_t rest = tile - nblocked;

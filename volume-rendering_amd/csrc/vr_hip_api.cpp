@@ -545,6 +545,7 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			for (int i = 0; i < 3; i++) { a.col_shade.dir[i] = p->view.direction[i]; a.col_shade.light[i] = p->view.light_pos[i]; }
 			a.col_shade.lh[0] = a.lh_x; a.col_shade.lh[1] = a.lh_y; a.col_shade.lh[2] = a.lh_z;
 			a.col_shade.kd_scaled = a.kd_scaled;
+			for (int i = 0; i < 3; i++) a.col_shade.dim[i] = c->dim[i];
 			a.col_shade.nbu = col_blocks(c->dim[m == 0 ? 1 : 0]);
 			a.col_shade.nw = col_windows(c->dim[m], nearest ? kColVoxCells : kColCells);
 			dual_analytic = false; dual_stage = -1;

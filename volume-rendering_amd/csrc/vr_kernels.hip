@@ -524,21 +524,27 @@ template <int I> __device__ __forceinline__ void managed_wait() {       // s_wai
 //      2  each XCD owns whole blocks, interleaved over the frame                                                   6.06 ms
 //    Concentrating a compact brick region on ONE L2 (1, 2) is markedly slower than letting all eight L2s serve it —
 //    the reuse between neighbouring tiles is small (the quad elements already carry the +1 neighbours) and a compact
-//    region exercises few L2 channels — so the plain interleave (0) is the default.  Placement affects speed only.
-#ifndef VR_XCD_MODE
-#define VR_XCD_MODE 0
+//    region exercises few L2 channels.  Round 4 (C4 full march, 8 views): WHICH tiles of a block share an XCD matters a little —
+//      3  pairs of x-neighbours   2.43 ms (views 1 / 4 / 5)      4  2x2 quads   2.42      0  columns   2.43
+//      5  XCD x renders ROW x of each block: 2.38 on those views, 2.069 against 2.093 over all eight (x-neighbours read
+//         neighbouring bricks of the x-fastest brick order); frames that launch in a measured-cost order: 0.599 against 0.594.
+//    Placement affects speed only.  5 is the numbering of the tiles inside a block (column-major), the same for every frame, and
+//    the host's tile_number_to_xy (vr_device.h, where VR_XCD_MODE is defined) follows it.
+#ifndef VR_COL_XCD_MODE
+#define VR_COL_XCD_MODE 0              // the column kernels' own choice
 #endif
 constexpr uint32_t kTileBlock = VR_TILE_ORDER > 1 ? VR_TILE_ORDER : 1;
 // tile number (the launch-order entry, or the workgroup id `bid`) -> workgroup tile column / row
+template <int XCD_MODE = VR_XCD_MODE>
 __device__ __forceinline__ void tile_to_xy(uint32_t tiles_x, uint32_t tiles_y, uint32_t tile, uint32_t bid, uint32_t &tile_x, uint32_t &tile_y) {
 	constexpr uint32_t B = kTileBlock;
 	const uint32_t ntiles = tiles_x * tiles_y;
 	const uint32_t full_cols = tiles_x / B, full_rows = tiles_y / B;
 	const uint32_t nblocked = full_cols * full_rows * B * B;          // tiles that lie in complete BxB blocks
-	if (VR_XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
+	if (XCD_MODE == 1) {                                           // contiguous chunk of the tile list per XCD
 		const uint32_t xcd = bid & 7u, slot = bid >> 3, q = ntiles >> 3, r = ntiles & 7u;
 		tile = xcd * q + (xcd < r ? xcd : r) + slot;
-	} else if (VR_XCD_MODE == 2) {                                    // whole blocks per XCD, interleaved over the frame
+	} else if (XCD_MODE == 2) {                                    // whole blocks per XCD, interleaved over the frame
 		const uint32_t covered = (nblocked / (8u * B * B)) * (8u * B * B);
 		if (bid < covered) {
 			const uint32_t set = bid / (8u * B * B), within = bid - set * (8u * B * B);
@@ -555,7 +561,14 @@ __device__ __forceinline__ void tile_to_xy(uint32_t tiles_x, uint32_t tiles_y, u
 			by = (by & 1u) ? full_rows / 2u - 1u - (by >> 1) : full_rows / 2u + (by >> 1);
 			bx = (bx & 1u) ? full_cols / 2u - 1u - (bx >> 1) : full_cols / 2u + (bx >> 1);
 #endif
-			tile_x = bx * B + in % B; tile_y = by * B + in / B;
+			uint32_t ix = in % B, iy = in / B;
+			if (B == 8 && XCD_MODE >= 3) {                // which tiles of a block share an XCD (= in & 7 in workgroup order): 3 pairs along x, 4 2x2 quads, 5 rows
+				const uint32_t xcd = in & 7u, slot = in >> 3;
+				if (XCD_MODE == 3) { ix = ((xcd & 3u) << 1) | (slot & 1u); iy = ((slot >> 1) << 1) | (xcd >> 2); }
+				else if (XCD_MODE == 4) { ix = ((xcd & 3u) << 1) | (slot & 1u); iy = ((slot >> 1) & 1u) | ((xcd >> 2) << 1) | ((slot >> 2) << 2); }
+				else { ix = slot; iy = xcd; }
+			}
+			tile_x = bx * B + ix; tile_y = by * B + iy;
 		} else {                                      // ragged right / bottom margins: leftover tiles, row-major
 			uint32_t rest = tile - nblocked;
 			const uint32_t right_w = tiles_x - full_cols * B, right_n = right_w * full_rows * B;
@@ -1124,9 +1137,6 @@ void raymarch_kernel(const RayKernelArgs a, const void *__restrict__ vol, const 
 #define VR_COL_DEPTH 3
 #endif
 constexpr int kColDepth = VR_COL_DEPTH, kColSlots = kColDepth + 1;
-#ifndef VR_COL_ISSUE_LATE
-#define VR_COL_ISSUE_LATE 0            // 1: the next window's gather is issued behind a dense window's samples (measured: 1.72 / 1.78 / 2.25 ms against 1.70 / 1.75 / 2.23)
-#endif
 
 __device__ __forceinline__ void managed_load128_s(u32x4 &dst, uint32_t byte_offset, uint64_t base) {     // window gather: scalar base + per-lane offset
 	asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(byte_offset), "s"(base));
@@ -1179,7 +1189,7 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 	}
 	__syncthreads();
 	uint32_t tile_x, tile_y;
-	tile_to_xy(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
+	tile_to_xy<VR_COL_XCD_MODE>(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
 	// pixel of this lane: the general kernel's mapping (lane order, 8x8 waves, tile phase)
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, qd = lane >> 4;
 	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;
@@ -1506,17 +1516,14 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 			static_for<0, kColDepth>([&](auto j) { issue(slot[j.value]); });
 			auto window_step = [&](auto jc) {
 				constexpr int c = decltype(jc)::value, n = (c + kColDepth) % kColSlots;
-				// (VR_COL_ISSUE_LATE, an experiment kept as a switch: the gather of the window kColDepth ahead issued AFTER this window's samples when
-				// the window is dense — the shading fetch of a composited sample returns behind every gather issued before it, and one issued
-				// just now is a whole HBM round trip away.  Not faster: the transparent windows behind a dense region then wait for their data.)
-				if (!VR_COL_ISSUE_LATE) issue(slot[n]);
+				issue(slot[n]);
 				__builtin_amdgcn_sched_barrier(0);
-				pin(slot[c]); managed_wait<(VR_COL_ISSUE_LATE ? kColDepth - 1 : kColDepth)>(); pin(slot[c]);
+				pin(slot[c]); managed_wait<kColDepth>(); pin(slot[c]);
 				const u32x4 o = slot[c];
 				if (c == 0) live &= __builtin_amdgcn_fcmpf(rlane(kvec, pos), ky, kFcmpOLE);      // lazy exit test: once per rotation of the slots (and by every sample that composites)
 				bool careful = false;                                       // an event window: some lane changes its column somewhere inside
 				if (kFlips) {
-					const int key = issue_key - (kColDepth + (VR_COL_ISSUE_LATE ? 0 : 1));               // = dsign * cur: the issue frontier is kColDepth windows ahead
+					const int key = issue_key - (kColDepth + 1);               // = dsign * cur: the issue frontier is kColDepth windows ahead and has just moved on
 					while (key > cons_event) { cons_at++; cons_event = __builtin_amdgcn_readlane(events, cons_at & 63); }
 					careful = key == cons_event;
 				}
@@ -1526,7 +1533,6 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 				if ((__builtin_amdgcn_uicmp(all4, a.skip_cmp, kIcmpNE) & live) != 0ull) dense = dense || VR_OPEN_LANES(acc.w, live) != 0ull;
 #endif
 				if (!dense) {
-					if (VR_COL_ISSUE_LATE) issue(slot[n]);
 					// a transparent window: its samples — consecutive lanes of the batch, from pos — just pass.  A window holds at most 3 * 64 + 1
 					// samples (a sample advances >= 1/64 cell, checked above), i.e. it ends within four batches: the bound is a hang guard
 					for (int batches = 0; batches < 5; batches++) {
@@ -1560,7 +1566,6 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 						refill(); pos = 0;
 					}
 					pos = pos < 64 ? pos : 63;
-					if (VR_COL_ISSUE_LATE) issue(slot[n]);
 				}
 				cur += dsign;
 			};
@@ -1612,7 +1617,7 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 	}
 	__syncthreads();
 	uint32_t tile_x, tile_y;
-	tile_to_xy(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
+	tile_to_xy<VR_COL_XCD_MODE>(a.tiles_x, a.tiles_y, blockIdx.x, blockIdx.x, tile_x, tile_y);
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, qd = lane >> 4;
 	uint32_t gu = lane & 3u, gv = (lane >> 2) & 3u;
 	const uint32_t order = a.lane_map & 3u;
@@ -1690,15 +1695,31 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 			uint32_t idx = s / VR_TF_RATIO;
 			asm volatile("" : "+v"(idx));
 			f4 cur = tf_l[idx & (VR_TF_SIZE - 1u)];
-			const float kd = q->p.light_kd;
+			const float kd = q->col_sample.light_kd, threshold = q->col_sample.ray_threshold;      // (adjacent: one scalar load)
+			hold_scalars(kd, threshold);
 			const uint64_t shaded = kd > 0.01f ? (__builtin_amdgcn_fcmpf(cur.w, 0.05f, kFcmpOGT) & live) : 0ull;
 			if (shaded != 0ull) {                                                             // RaycasterBase.h:87-98 shade
-				const f3 pt = position(q, k);
-				const f3 d = mk3(q->p.view.light_pos[0] - pt.x, q->p.view.light_pos[1] - pt.y, q->p.view.light_pos[2] - pt.z);
+				// everything the shading needs from the argument segment in ONE scalar load (see colmarch_kernel), beside the LDS read of the origin
+				const f3 o = origin_again();
+				RayKernelArgs::ColDenseShade dh;
+				for (int i = 0; i < 3; i++) { dh.dir[i] = q->col_shade.dir[i]; dh.light[i] = q->col_shade.light[i]; dh.dim[i] = q->col_shade.dim[i]; }
+				dh.nbu = q->col_shade.nbu; dh.nw = q->col_shade.nw;
+				const uint8_t *const copy_p = ((ConstKernelArguments) q)->copy;
+				hold_scalars(dh.dir[0], dh.dir[1], dh.dir[2], dh.light[0], dh.light[1], dh.light[2], dh.dim[0], dh.dim[1], dh.dim[2], dh.nbu, dh.nw, (uint64_t) (uintptr_t) copy_p);
+				const f3 pt = mk3(o.x + dh.dir[0] * k, o.y + dh.dir[1] * k, o.z + dh.dir[2] * k);        // position(q, k)
+				const f3 d = mk3(dh.light[0] - pt.x, dh.light[1] - pt.y, dh.light[2] - pt.z);
 				const float inv = 1.0f / __builtin_sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
 				const f3 l = mk3(d.x * inv, d.y * inv, d.z * inv);
 				const f3 ps = mk3(pt.x + l.x * 0.01f, pt.y + l.y * 0.01f, pt.z + l.z * 0.01f);
-				const uint32_t s_l = *voxel_address(q, ps);
+				uint32_t s_l;
+				{   // voxel_address(q, ps) with the constants held above
+					const uint32_t ix = map_float_int((ps.x + 1) * 0.5f, dh.dim[0]), iy = map_float_int((ps.y + 1) * 0.5f, dh.dim[1]), iz = map_float_int((ps.z + 1) * 0.5f, dh.dim[2]);
+					const uint32_t iu = U == 0 ? ix : iy, iv = V == 1 ? iy : iz, im = M == 0 ? ix : (M == 1 ? iy : iz);
+					const uint32_t block = ((iv >> kColEdgeLog2) * dh.nbu + (iu >> kColEdgeLog2)) * dh.nw + (im >> 4);
+					const uint32_t in_block = (iv & kColEdgeMask) * kColRowBytes + (iu & kColEdgeMask) * kColWindowBytes + (im & 15u);
+					const uint8_t *p = copy_p + ((uint64_t) block * kColBlockBytes + in_block);
+					s_l = *VR_BC_POINTER(a, const uint8_t *, p, 1u);
+				}
 				const float sl = unit_l[s_l], sc = unit_l[s & 255u];                          // RaycasterBase.h:93-96
 				const float diffuse = select_lanes(shaded, (sl - sc) * kd);
 				cur.x += diffuse; cur.y += diffuse; cur.z += diffuse;
@@ -1706,7 +1727,7 @@ void colmarch_nearest_kernel(const RayKernelArgs a, const uint8_t *__restrict__ 
 			const float t = select_lanes(live, 1 - acc.w);                                    // CPURenderer.cpp:34
 			acc.x = acc.x + cur.x * t; acc.y = acc.y + cur.y * t;
 			acc.z = acc.z + cur.z * t; acc.w = acc.w + cur.w * t;
-			live &= ~__builtin_amdgcn_fcmpf(acc.w, q->p.ray_threshold, kFcmpOGT);             // CPURenderer.cpp:35-36
+			live &= ~__builtin_amdgcn_fcmpf(acc.w, threshold, kFcmpOGT);                      // CPURenderer.cpp:35-36
 		}
 	};
 
