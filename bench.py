@@ -463,6 +463,8 @@ def run_rank(a):
                 "traffic_GBs": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9, 1) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
                 # what the kernel actually moves against the HBM peak (the copies it reads are 4 - 4.5 bytes per voxel and fetched 1 - 2.4 times)
                 "traffic_frac_of_peak": (round(traffic["bytes_per_launch"] / (traffic["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic.get("bytes_per_launch") and traffic.get("kernel_ms") else None),
+                # the other bound: vector-issue utilisation per benchmark view, from the counters of the same evidence run (profiles/, not live)
+                "valu_busy_per_view": traffic.get("valu_busy_per_view"),
                 "kernel": "vr::raymarch_kernel + vr::colmarch_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernel_instantiations": "the frame's ONE launch is colmarch_kernel<sampling, axis, flips> (NEAREST: colmarch_nearest_kernel<axis, flips>) for frames without leaping of orthogonal views along a volume axis "
@@ -474,7 +476,8 @@ def run_rank(a):
                                    "launch that shares the chip with its neighbour — longer than the kernel alone; `value` (frames per second over all ranks) is the figure "
                                    "that counts, `scale_model` at N = 1 holds the per-rank kernel times without overlap") if slot_streams[0] is not slot_streams[1] else None,
                 "kernel_imbalance_max_over_mean": round(max(per_rank_kernel_ms) / (sum(per_rank_kernel_ms) / len(per_rank_kernel_ms)), 4),
-                "note": "the column-window views are HBM bound (5.7 GB of copy per frame at 4.3 TB/s), the others gather / VALU-issue bound (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "
+                "note": "the lit march is bound by vector-instruction issue as much as by memory (valu_busy_per_view 0.5 - 0.9; the column-window views stream 5.7 GB of copy per frame at 4.3 TB/s "
+                        "when unlit), the run-brick views also by the gather rate of the L1 (SURVEY §8d 'honest ceiling'); every voxel is still fetched — the "
                         "exact per-wave shortcuts (transparent samples, rays whose accumulated alpha is exactly 1) skip arithmetic only"}
             out["minmax_feeder"] = {"kernel": "vr::minmax_kernel", "kernel_ms": round(minmax_ms, 4),
                                     "achieved_GBs": round(n ** 3 / (minmax_ms * 1e-3) / 1e9, 1),

@@ -14,8 +14,9 @@ print('value', d['value'], 'ms', d['ms_per_step'], 'kernel', d['roofline']['kern
 PY
 bash scripts/profile_bench.sh r04 > $O/profile.log 2>&1 || { tail -20 $O/profile.log; exit 1; }
 grep -E "timed_mean|FETCH_SIZE|WRITE_SIZE" $O/profile.log
-bash scripts/gpu_pmc.sh gpurun_out/r04_pmc_u8 sq2,tcc,fetch,tcp1 --mode nooptims --views 0,1,2,3,4,5,6,7 > $O/pmc_u8.log 2>&1 || { tail -10 $O/pmc_u8.log; exit 1; }
+bash scripts/gpu_pmc.sh gpurun_out/r04_pmc_u8 sq1,sq2,tcc,fetch,tcp1 --mode nooptims --views 0,1,2,3,4,5,6,7 > $O/pmc_u8.log 2>&1 || { tail -10 $O/pmc_u8.log; exit 1; }
 python scripts/pmc_per_view.py gpurun_out/r04_pmc_u8 6 march_kernel 2 > $O/per_view_pmc_u8.txt; cat $O/per_view_pmc_u8.txt
+python scripts/valu_busy.py $O/per_view_pmc_u8.txt > $O/valu_busy_u8.txt; cat $O/valu_busy_u8.txt
 timeout -k 10 150 python scripts/perf_probe.py --mode nooptims --bpv 2 --reps 4 > $O/u16_ms.json 2>> $O/probe.err || { tail -5 $O/probe.err; exit 1; }
 cut -c1-400 $O/u16_ms.json
 bash scripts/gpu_pmc.sh gpurun_out/r04_pmc_u16 sq2,tcc,fetch,tcp1 --mode nooptims --bpv 2 --views 0,1,2,3,4,5,6,7 > $O/pmc_u16.log 2>&1 || { tail -10 $O/pmc_u16.log; exit 1; }

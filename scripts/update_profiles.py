@@ -28,8 +28,15 @@ for line in open(os.path.join(src, "pmc_summary.txt")):
 with open(os.path.join(src, "stats_bench.json")) as f:
     bench = json.loads([ln for ln in f if ln.startswith("{")][-1])
 traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-json.dump({"nooptims_trilinear_1024_2048_n1": {"bytes_per_launch": round(traffic), "commit": commit,
-                                               "kernel_ms": bench["roofline"]["kernel_ms"]},
+entry = {"bytes_per_launch": round(traffic), "commit": commit, "kernel_ms": bench["roofline"]["kernel_ms"]}
+busy_file = os.path.join(ROOT, "gpurun_out", f"{rnd}_k", "valu_busy_u8.txt")       # scripts/valu_busy.py over the per-view counters of the same evidence run
+if os.path.exists(busy_file):
+    for line in open(busy_file):
+        if line.startswith("VALU busy"):
+            entry["valu_busy_per_view"] = [float(x) for x in line.split()[2:]]
+            entry["valu_busy_note"] = ("share of the SIMDs' issue cycles that carried a vector ALU instruction, per benchmark view (SQ_ACTIVE_INST_VALU x 4 / "
+                                       "(1024 SIMDs x GRBM_GUI_ACTIVE / 8), scripts/valu_busy.py): what bounds the lit march beside the memory path")
+json.dump({"nooptims_trilinear_1024_2048_n1": entry,
            "_source": f"profiles/{rnd}_bench_pmc_summary.txt: mean over the 16 TIMED raymarch launches of rocprofv3 --pmc FETCH_SIZE "
                       f"({vals['FETCH_SIZE']:.6g} KB, x2: gfx950 tallies 128-B requests at 64 B, calibrated on minmax_kernel which reads "
                       f"exactly 1 GiB and reports 524312 KB) + WRITE_SIZE ({vals['WRITE_SIZE']:.6g} KB, exact), separate passes",

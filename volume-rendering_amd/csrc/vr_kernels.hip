@@ -1526,6 +1526,9 @@ void colmarch_kernel(const RayKernelArgs a, const uint8_t *__restrict__ copy, co
 					const int key = issue_key - (kColDepth + 1);               // = dsign * cur: the issue frontier is kColDepth windows ahead and has just moved on
 					while (key > cons_event) { cons_at++; cons_event = __builtin_amdgcn_readlane(events, cons_at & 63); }
 					careful = key == cons_event;
+#ifdef VR_COL_EXP_NO_CAREFUL          // timing-only experiment: event windows are treated like any other (wrong pixels where a ray changes its column)
+					careful = false;
+#endif
 				}
 				const uint32_t all4 = (o.x | o.y | o.z | o.w) & a.skip_mask;
 				bool dense = careful;
