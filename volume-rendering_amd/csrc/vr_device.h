@@ -282,10 +282,12 @@ hipError_t launch_raymarch(const RayKernelArgs &a, const void *linear, const voi
 
 // what launch_raymarch will do with these arguments: whether the variant reads the LINEAR array (refused once that was released),
 // and its grid of workgroup tiles (32x16 pixels, 32x32 for the 64-bit address tables)
-struct RaymarchPlan { bool reads_linear; uint32_t tiles_x, tiles_y; };
+struct RaymarchPlan { bool reads_linear; uint32_t tiles_x, tiles_y; uint32_t tile_h = 16; /* rows of a workgroup tile (32 pixels wide) */ };
 RaymarchPlan plan_raymarch(const RayKernelArgs &a, bool have_bricked, uint32_t bytes_per_voxel);
 // cost[ntiles] (recorded by a frame) -> order[ntiles] for the next frame with the same parameters; clears cost
 hipError_t launch_tile_order(uint32_t *cost, uint32_t *order, uint32_t ntiles, hipStream_t stream);
+// predicted cost[ntiles] for a frame that leaps and has no recording yet (a.tiles_x / tiles_y / phase filled in; tile_h = rows of a workgroup tile)
+hipError_t launch_tile_estimate(const RayKernelArgs &a, uint32_t tile_h, const uint32_t *esl, uint32_t *cost, uint32_t ntiles, hipStream_t stream);
 // kLayoutRunDual: choice[t] = t | (cost_y[t] < cost_z[t] ? kTileAltBit : 0); both costs NULL = alternating tiles (testing)
 hipError_t launch_tile_choice(const uint32_t *cost_z, const uint32_t *cost_y, uint32_t *choice, uint32_t ntiles, hipStream_t stream);
 

@@ -649,6 +649,32 @@ int launch_frame(vr_ctx *c, const vr_params *p, void *dev_rgba, hipStream_t stre
 			VR_TRY(c, hipStreamWaitEvent(stream, pending_elsewhere->ready, 0));
 			read_slot = pending_elsewhere;
 		}
+		// No order at all — the first frame under this policy key (a new view: the reference's benchmark renders every view once): predict
+		// the tile costs from the ESL bit volume (tile_estimate_kernel) and order by them, on this stream, in front of the frame
+		static const bool estimate = [] { const char *e = getenv("VR_TILE_ESTIMATE"); return e == nullptr || atoi(e) != 0; }();      // VR_TILE_ESTIMATE=0: A/B
+		if (read_slot == nullptr && estimate && p->esl && a.layout != kLayoutColumn) {
+			vr_ctx::SchedSlot *est = nullptr;
+			for (auto &sl : oe->slot) {
+				if (sl.last_seq > c->completed_seq) continue;                                          // a frame that may still run reads or records it
+				if (sl.ready != nullptr && sl.issue_seq != 0) { const hipError_t q = hipEventQuery(sl.ready); if (q != hipSuccess) { (void) hipGetLastError(); continue; } }
+				est = &sl; break;
+			}
+			if (est != nullptr && est->capacity < ntiles) {
+				if (est->cost) { (void) hipFree(est->cost); (void) hipFree(est->order); est->cost = est->order = nullptr; est->capacity = 0; }
+				if (hipMalloc((void **) &est->cost, (size_t) ntiles * 4) == hipSuccess && hipMalloc((void **) &est->order, (size_t) ntiles * 4) == hipSuccess) est->capacity = ntiles;
+				else { (void) hipGetLastError(); if (est->cost) (void) hipFree(est->cost); est->cost = est->order = nullptr; est = nullptr; }
+			}
+			if (est != nullptr) {
+				if (est->ready == nullptr) VR_TRY(c, hipEventCreateWithFlags(&est->ready, hipEventDisableTiming));
+				RayKernelArgs ea = a;
+				ea.tiles_x = plan.tiles_x; ea.tiles_y = plan.tiles_y;
+				VR_TRY(c, launch_tile_estimate(ea, plan.tile_h, c->esl, est->cost, ntiles, stream));
+				VR_TRY(c, launch_tile_order(est->cost, est->order, ntiles, stream));
+				VR_TRY(c, hipEventRecord(est->ready, stream));
+				est->valid = true; est->ntiles = ntiles; est->stream = stream; est->issue_seq = c->seq_next;
+				read_slot = est;
+			}
+		}
 		if (read_slot != nullptr) sched.order = read_slot->order;
 		// record this frame's tile costs?  Always while the parameters keep changing (a moving camera: the next frame's order comes from
 		// this one), twice for a frame that is repeated unchanged (the first recording of a view may have run on cold caches)
