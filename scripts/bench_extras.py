@@ -62,7 +62,9 @@ def first_visit_leg(vr, r, scene, W, H, buf, stream, sync, modes=("nooptims", "d
         return r.timing().kernel_ms
 
     out = {"what": "first frames (no earlier frame with the same parameters: the reference's one-frame-per-view benchmark protocol, and a camera "
-                   "that moves every frame) against repeated frames; kernel ms (hipEvents); copies already resident"}
+                   "that moves every frame) against repeated frames; kernel ms (hipEvents); copies already resident.  In the leaping modes the first frame of a view launches in a PREDICTED order "
+                   "(tile costs estimated from the ESL bit volume): tile_estimate_kernel + tile_order_kernel run in front of it, 0.035 ms together "
+                   "(profiles/r04_first_visit_prepass.txt), which these kernel times do not include"}
     for mode in modes:
         set_mode(scene, mode)
         for sname in samplings:

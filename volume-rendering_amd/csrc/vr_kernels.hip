@@ -2090,53 +2090,76 @@ constexpr uint32_t kOrderBins = VR_ORDER_BINS, kOrderThreads = 512;
 
 __global__ __launch_bounds__(kOrderThreads)
 void tile_order_kernel(uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t ntiles) {
-	__shared__ uint32_t count[kOrderBins][kOrderThreads + 1];
+	__shared__ uint32_t wave_total[kOrderBins][kOrderThreads / 64u], bin_total[kOrderBins];
 	__shared__ uint32_t vmax;
+	// up to kOrderCached tiles (a 2048^2 frame has 8192) the costs are read ONCE, coalesced, into LDS and the three passes below run on that
+	// copy (each thread owns a contiguous run of tiles, i.e. strided global reads otherwise); larger frames read them from memory
+	constexpr uint32_t kOrderCached = 8192;
+	__shared__ uint32_t cached[kOrderCached];
 	const uint32_t t = threadIdx.x;
 	const uint32_t chunk = (ntiles + kOrderThreads - 1) / kOrderThreads, lo = t * chunk < ntiles ? t * chunk : ntiles, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+	const bool in_lds = ntiles <= kOrderCached;
+	if (in_lds) for (uint32_t i = t; i < ntiles; i += kOrderThreads) { cached[i] = cost[i]; cost[i] = 0; }      // (cleared for the next recording on the way)
 	if (t == 0) vmax = 0;
 	__syncthreads();
+	auto cost_of = [&](uint32_t i) { return in_lds ? cached[i] : cost[i]; };
 	uint32_t m = 0;
-	for (uint32_t i = lo; i < hi; i++) m = cost[i] > m ? cost[i] : m;
+	for (uint32_t i = lo; i < hi; i++) { const uint32_t c = cost_of(i); m = c > m ? c : m; }
 	atomicMax(&vmax, m);
 	__syncthreads();
-	const uint64_t top = (uint64_t) vmax + 1;
-	auto bin_of = [&](uint32_t c) { return kOrderBins - 1u - (uint32_t) (((uint64_t) c * kOrderBins) / top); };    // 0 = most expensive
+	// (bins by a float product: the 64-bit division the first version used here, twice per tile, was most of the kernel's 25 us; any
+	// monotone function does as long as both passes use the same one)
+	const float scale = (float) kOrderBins / ((float) vmax + 1.0f);
+	auto bin_of = [&](uint32_t c) { const uint32_t q = (uint32_t) ((float) c * scale); return kOrderBins - 1u - (q < kOrderBins ? q : kOrderBins - 1u); };    // 0 = most expensive
 	uint32_t mine[kOrderBins];
 	for (uint32_t b = 0; b < kOrderBins; b++) mine[b] = 0;
-	for (uint32_t i = lo; i < hi; i++) mine[bin_of(cost[i])]++;
-	for (uint32_t b = 0; b < kOrderBins; b++) count[b][t] = mine[b];
+	for (uint32_t i = lo; i < hi; i++) mine[bin_of(cost_of(i))]++;
+	// exclusive scan of every bin's per-thread counts over the 512 threads: inside a wave by shuffles, across the 8 waves through LDS
+	// (the first version scanned each bin serially in one thread: 22 of the kernel's 26 us)
+	const uint32_t lane = t & 63u, wave = t >> 6;
+	uint32_t before[kOrderBins];
+	for (uint32_t b = 0; b < kOrderBins; b++) {
+		uint32_t v = mine[b];
+		#pragma unroll
+		for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t n = __shfl_up(v, d, 64); if (lane >= d) v += n; }
+		before[b] = v - mine[b];
+		if (lane == 63u) wave_total[b][wave] = v;
+	}
 	__syncthreads();
-	if (t < kOrderBins) {                                   // exclusive scan of one bin's per-thread counts; total in the last slot
+	if (t < kOrderBins) {
 		uint32_t run = 0;
-		for (uint32_t i = 0; i < kOrderThreads; i++) { const uint32_t c = count[t][i]; count[t][i] = run; run += c; }
-		count[t][kOrderThreads] = run;
+		for (uint32_t w = 0; w < kOrderThreads / 64u; w++) { const uint32_t c = wave_total[t][w]; wave_total[t][w] = run; run += c; }
+		bin_total[t] = run;
 	}
 	__syncthreads();
 	uint32_t base = 0, pos[kOrderBins];
-	for (uint32_t b = 0; b < kOrderBins; b++) { pos[b] = base + count[b][t]; base += count[b][kOrderThreads]; }
-	for (uint32_t i = lo; i < hi; i++) { order[pos[bin_of(cost[i])]++] = i; }
-	__syncthreads();
-	for (uint32_t i = lo; i < hi; i++) cost[i] = 0;
+	for (uint32_t b = 0; b < kOrderBins; b++) { pos[b] = base + wave_total[b][wave] + before[b]; base += bin_total[b]; }
+	for (uint32_t i = lo; i < hi; i++) { order[pos[bin_of(cost_of(i))]++] = i; }
+	if (!in_lds) {
+		__syncthreads();
+		for (uint32_t i = lo; i < hi; i++) cost[i] = 0;
+	}
 }
 
 // ---- a launch order for the FIRST frame of a policy key (round 4) ------------------------------------------------------------------
 // A frame that leaps has no recorded costs yet when its view is new (the reference's benchmark renders every view once): this kernel
-// predicts them.  One thread per workgroup tile walks five of the tile's rays (centre and four inner points) through the 32^3 ESL bit
-// volume in half-block strides and counts the strides that lie in non-empty blocks: cost = the longest such stretch in samples + one per
-// stride probed (what the ESL loop pays in empty space).  Early ray termination is not modelled (an upper estimate for opaque regions).
+// predicts them.  Eight lanes per workgroup tile walk one ray each (the centres of the tile's eighths) through the 32^3 ESL bit volume in
+// half-block strides and count the strides that lie in non-empty blocks: cost = the largest such count in samples + one per stride
+// probed (what the ESL loop pays in empty space).  Early ray termination is not modelled (an upper estimate for opaque regions).
 // Feeds tile_order_kernel like a recording does.  Placement only: the image does not depend on it.
 __global__ __launch_bounds__(256)
 void tile_estimate_kernel(const RayKernelArgs a, uint32_t tile_h, const uint32_t *__restrict__ esl_g, uint32_t *__restrict__ cost, uint32_t ntiles) {
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	if (t >= ntiles) return;
-	uint32_t tile_x, tile_y;
-	tile_to_xy(a.tiles_x, a.tiles_y, t, t, tile_x, tile_y);
+	const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t t = gid >> 3, probe = gid & 7u;                      // eight lanes per tile, one ray each
+	uint32_t tile_x = 0, tile_y = 0;
+	if (t < ntiles) tile_to_xy(a.tiles_x, a.tiles_y, t, t, tile_x, tile_y);
 	const f3 vo = ld3(a.p.view.origin), vd = ld3(a.p.view.direction), vr_ = ld3(a.p.view.right_plane), vu = ld3(a.p.view.up_plane);
 	const float edge = flmin(flmin(a.p.esl_block_size[0], a.p.esl_block_size[1]), a.p.esl_block_size[2]);
 	uint32_t best = 0;
-	for (uint32_t probe = 0; probe < 5u; probe++) {
-		const uint32_t px = probe == 0u ? 16u : ((probe & 1u) ? 6u : 25u), py = probe == 0u ? tile_h / 2u : ((probe & 2u) ? tile_h / 5u : tile_h - 1u - tile_h / 5u);
+	do {
+		if (t >= ntiles) break;
+		// the centres of the tile's 4 x 2 eighths (one 8x8-pixel wave each in the 32x16 tile)
+		const uint32_t px = (probe & 3u) * 8u + 4u, py = (probe >> 2) * (tile_h / 2u) + tile_h / 4u;
 		const uint32_t lx = tile_x * 32u + px - a.phase_x, ly = tile_y * tile_h + py - a.phase_y;
 		if (lx >= a.p.out_width || ly >= a.p.out_rows) continue;
 		const uint32_t band = ly / a.p.band_rows;
@@ -2162,14 +2185,15 @@ void tile_estimate_kernel(const RayKernelArgs a, uint32_t tile_h, const uint32_t
 		}
 		const float samples_per_stride = dk / flmax(a.p.ray_step, 1e-9f);
 		const float est = (float) full * flmin(samples_per_stride, 4096.0f) + (float) strides;
-		const uint32_t e = est > 4.0e9f ? 4000000000u : (uint32_t) est;
-		best = e > best ? e : best;
-	}
-	cost[t] = best;
+		best = est > 4.0e9f ? 4000000000u : (uint32_t) est;
+	} while (false);
+	#pragma unroll
+	for (uint32_t d = 1; d < 8u; d <<= 1) { const uint32_t o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+	if (probe == 0u && t < ntiles) cost[t] = best;
 }
 
 hipError_t launch_tile_estimate(const RayKernelArgs &a, uint32_t tile_h, const uint32_t *esl, uint32_t *cost, uint32_t ntiles, hipStream_t stream) {
-	hipLaunchKernelGGL(tile_estimate_kernel, dim3((ntiles + 255u) / 256u), dim3(256), 0, stream, a, tile_h, esl, cost, ntiles);
+	hipLaunchKernelGGL(tile_estimate_kernel, dim3((ntiles * 8u + 255u) / 256u), dim3(256), 0, stream, a, tile_h, esl, cost, ntiles);
 	return hipGetLastError();
 }
 
