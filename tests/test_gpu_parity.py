@@ -776,3 +776,45 @@ def test_feeders_minmax_histogram_generate(vr, gpu, golden, oracle):
         assert bd == obd and np.array_equal(mm, omm), (n, bpv, kind)
         h, _ = gpu.volume_histogram()
         assert np.array_equal(h, oracle.histogram(vox))
+
+
+def test_host_buffer_slices_equal_one_launch(vr):
+    """vr_hip_render (the reference's host-buffer entry point) renders a frame of unpartitioned rows as two row slices on two streams so
+    that the first slice's copy to the host overlaps the second slice (VR_HOST_SLICES=1: one launch + one copy).  Same bytes either way,
+    for a frame whose rows are no multiple of the tile height, in a leaping and in the full-march mode, from an oblique and an axis-aligned
+    pose (general and column kernels), and equal to the device-pointer entry point."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    child = r"""
+import importlib, hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+vr = importlib.import_module("volume-rendering_amd")
+r = vr.HipRenderer(0)
+r.generate_volume("shell", 192, seed=3)
+scene = vr.Scene().set_volume(dims=(192, 192, 192), minmax=r.volume_minmax()[0])
+r.set_transfer_fn(scene.tf, scene.esl)
+W, H = 1000, 777
+r.set_window_buffer(W, H)
+dev = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda:0")
+for mode in ("default", "nooptims"):
+    scene.set_modes(esl=(mode == "default"), ray_threshold=(0.95 if mode == "default" else 1.0), light_kd=0.6)
+    for view in (0, 1, 5):
+        for samp in (vr.SAMPLE_TRILINEAR, vr.SAMPLE_NEAREST):
+            p = scene.frame_params(vr.benchmark_view(W, H, view), samp)
+            host = r.render_volume(p)
+            r.render_volume_device(p, dev.data_ptr())
+            torch.cuda.synchronize()
+            assert (dev.cpu().numpy() == host).all(), (mode, view, samp)
+            print(mode, view, samp, hashlib.sha1(host.tobytes()).hexdigest(), int((host[..., 3] != 0).sum()))
+"""
+    outs = []
+    for slices in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", child % {"root": ROOT}], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, VR_HOST_SLICES=slices))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == 12
+    assert all(int(line.split()[-1]) > 1000 for line in outs[0].strip().splitlines())     # the frames are not empty
