@@ -179,7 +179,9 @@ int vr_hip_read_tile_costs(vr_ctx *ctx, uint32_t *host_out, uint32_t capacity, u
 
 /* ---- Renderer::render_volume(uchar4 *buffer, Raycaster r) ----
  * vr_hip_render: `host_rgba` is a HOST pointer of out_width*out_rows*4 bytes (renderer ids 0-2 in the reference,
- *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.
+ *   VolR.cpp:76-87; GPURenderer1.cu:107-110 = clear + kernel + D2H).  Synchronous.  A frame of unpartitioned rows (band_stride 1) of
+ *   at least 1 MiB is rendered as two row slices on two streams of the context, so that the first slice's copy to the host runs while
+ *   the second still renders; the bytes written are the same (VR_HOST_SLICES=1: one launch + one copy).
  * vr_hip_render_device: `dev_rgba` is a DEVICE pointer (renderer ids 3-4, GPURenderer23.cu:72-81) — clear + kernel on
  *   `stream` (a hipStream_t).  NULL means the context's OWN non-blocking stream, which is not ordered against the legacy
  *   default stream: a caller that fills or reads `dev_rgba` on another stream must pass that stream (or synchronise itself).
